@@ -1,0 +1,167 @@
+/*
+ * adsb_amd.h -- C ABI of libadsb_amd.so: an MI355X (gfx950) IQ -> Mode S frame demodulator that
+ * replaces the body of libadsb's 1090 handler while keeping its handler/listener surface.
+ *
+ * Boundary being replaced (all citations into the reference tree, ankurvdev/libadsb):
+ *   RTLSDR::IDataHandler::HandleData(std::span<uint8_t const> const&)      RTLSDR.hpp:39-49
+ *   ADSB1090Handler::HandleData -> DetectModeS -> DecodeModesMessage ...     ADSB1090.cpp:158-175, 741-959, 491-675
+ *   ADSB::IListener::OnChanged(IAirCraft const&) via TrafficManager          ADSBListener.h:52-60, AircraftImpl.h:49-68
+ *   factories ADSB::TryCreateADSB1090Handler / ADSB::test::...               ADSB.h:13-15, 24-26
+ *   UAT: extern "C" init_fec / process_buffer / dump_raw_message            UAT978.cpp:9-10, uat2json-wrapper.cpp:7,14
+ *
+ * The reference has no C ABI for 1090 (the handler is a C++ class); this header is the seam a
+ * maintainer binds instead of compiling ADSB1090.cpp -- INTEGRATION.md shows the adapter.
+ *
+ * Two layers:
+ *   adsb_amd_ctx_t       GPU half: u8 IQ -> candidate records (rows a3-a10 of SURVEY.md section 8a)
+ *   adsb_amd_resolver_t  host half: records -> accepted frames -> aircraft state -> callback
+ *                        (rows a11-a14: ICAO cache, skip-ahead sequencing, field decode, CPR)
+ *   adsb_amd_handler_t   both, behind one HandleData-shaped call
+ *
+ * All functions return 0 on success or a negative ADSB_AMD_E* code; the message is available
+ * from *_last_error().  Nothing here falls back to a CPU demodulator: without a usable HIP
+ * device adsb_amd_create() fails.
+ */
+#ifndef ADSB_AMD_H
+#define ADSB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADSB_AMD_OK 0
+#define ADSB_AMD_ENODEV (-1)   /* no HIP device / HIP runtime error at creation */
+#define ADSB_AMD_EINVAL (-2)   /* bad argument (size, alignment, slot) */
+#define ADSB_AMD_EHIP (-3)     /* HIP runtime error during a call */
+#define ADSB_AMD_ENOSPC (-4)   /* caller's output array too small (n_out holds the needed count) */
+#define ADSB_AMD_ESTATE (-5)   /* fetch without submit, etc. */
+
+/* RTLSDR::BufferLength (RTLSDR.hpp:55): the unit the reference demodulates independently. */
+#define ADSB_AMD_REF_BUFFER_BYTES 262144u
+
+/* record.flags */
+#define ADSB_AMD_F_PASS2 0x01u      /* produced by the retry slice (reference useCorrection==true) */
+#define ADSB_AMD_F_PHASE 0x02u      /* the retry rescaled the window (DetectOutOfPhase != 0, j != 0) */
+#define ADSB_AMD_F_NEEDS_ICAO 0x04u /* DF0/4/5/16/20/21/24: valid only if `addr` is in the ICAO cache */
+
+/*
+ * One candidate frame emitted by the GPU (32 bytes, little endian).  A record is emitted for every
+ * offset that passes the preamble gates, the energy gate and has errors==0, and whose frame the
+ * reference could accept: DF11/17 with good or 1-bit-repairable parity (unconditional), or an
+ * AP-type DF (conditional on the ICAO cache, ADSB1090.cpp:396-435).  Up to two records per offset
+ * (first slice, then the phase-corrected retry).  Records are sorted by (buffer, offset, pass).
+ * The sequential rules of ADSB1090.cpp:886-957 (skip-ahead, cache gating) are applied afterwards
+ * by the resolver, on the host.
+ */
+typedef struct adsb_amd_record
+{
+    uint32_t buffer;   /* index of the reference buffer inside this scan call */
+    uint32_t offset;   /* sample index j of the preamble inside that buffer */
+    uint32_t addr;     /* DF11/17: bytes 1..3 after repair; AP-type: AP xor parity */
+    uint16_t delta;    /* energy-gate average (ADSB1090.cpp:870-872), saturated to 65535 */
+    uint8_t  nbits;    /* 56 / 112, from the DF as sliced (before repair) */
+    int8_t   errorbit; /* -1, or the repaired bit (FixSingleBitErrors) */
+    uint8_t  df;       /* msg[0]>>3 as sliced (before repair) -- Message::msgtype */
+    uint8_t  flags;    /* ADSB_AMD_F_* */
+    uint8_t  msg[14];  /* message bytes after repair */
+} adsb_amd_record_t;
+
+/* Accepted frame + aircraft snapshot handed to the callback (mirrors what IListener::OnChanged sees). */
+typedef struct adsb_amd_frame
+{
+    uint64_t offset; /* sample index inside the HandleData buffer (buffer * samples_per_buffer + j) */
+    uint8_t  msg[14];
+    uint8_t  nbits;
+    int8_t   errorbit;
+    uint8_t  pass;          /* 1 or 2 */
+    uint8_t  phase_applied;
+    uint8_t  df;
+    uint8_t  reserved;
+    uint32_t addr;
+} adsb_amd_frame_t;
+
+typedef struct adsb_amd_aircraft
+{
+    uint32_t addr;
+    char     callsign[8]; /* raw, not NUL terminated (AircraftImpl.h:31) */
+    int32_t  lat1e7, lon1e7;
+    int32_t  altitude;
+    uint32_t speed, track;
+    int32_t  vert_rate;
+    uint32_t squawk;
+} adsb_amd_aircraft_t;
+
+typedef void (*adsb_amd_on_changed_fn)(void* user, const adsb_amd_frame_t* frame, const adsb_amd_aircraft_t* aircraft);
+
+const char* adsb_amd_version(void);
+
+/* ---------------------------------------------------------------- GPU half */
+typedef struct adsb_amd_ctx adsb_amd_ctx_t;
+
+/* device < 0: current HIP device. */
+int         adsb_amd_create(adsb_amd_ctx_t** out, int device);
+void        adsb_amd_destroy(adsb_amd_ctx_t* ctx);
+const char* adsb_amd_last_error(const adsb_amd_ctx_t* ctx); /* ctx may be NULL: creation error */
+
+/*
+ * Synchronous scan of host memory (the HandleData case): copies `nbytes` of interleaved u8 I,Q to
+ * the device, demodulates, returns the sorted records.  The input is split into independent
+ * reference buffers of `buffer_bytes` (0: the whole input is one buffer, as in the reference's
+ * TestEmbedded); a trailing partial buffer is ignored, as the reference's replay does
+ * (RTLSDR.hpp:429-437).  Each buffer needs >= 480 bytes.
+ */
+int adsb_amd_scan_1090(adsb_amd_ctx_t* ctx, const uint8_t* iq_host, size_t nbytes, size_t buffer_bytes,
+                       adsb_amd_record_t* out, size_t cap, size_t* n_out);
+
+/*
+ * Asynchronous scan of device-resident input.  `slot` (0/1) selects one of two result buffers so
+ * that the device->host copy of one scan overlaps the kernels of the next.  `iq_device` must be
+ * 16-byte aligned and stay valid until the matching fetch.  `hip_stream` is a hipStream_t
+ * (NULL: the context's own stream).
+ */
+int adsb_amd_scan_1090_submit(adsb_amd_ctx_t* ctx, const void* iq_device, size_t nbytes, size_t buffer_bytes,
+                              void* hip_stream, int slot);
+/* Waits for the slot; *records points into context-owned pinned memory, valid until the next submit on that slot. */
+int adsb_amd_scan_1090_fetch(adsb_amd_ctx_t* ctx, int slot, const adsb_amd_record_t** records, size_t* n);
+/* Device time of the last completed scan on `slot`: the demodulation kernel alone, and submit-to-records-on-host. */
+int adsb_amd_scan_1090_timing(adsb_amd_ctx_t* ctx, int slot, float* scan_kernel_ms, float* total_ms);
+
+/* Parity helper: magnitudes exactly as ADSB1090.cpp:165-173 computes them (n = nbytes/2 values). */
+int adsb_amd_magnitude_1090(adsb_amd_ctx_t* ctx, const uint8_t* iq_host, size_t nbytes, uint16_t* mag_out);
+
+/* ---------------------------------------------------------------- host half */
+typedef struct adsb_amd_resolver adsb_amd_resolver_t;
+
+adsb_amd_resolver_t* adsb_amd_resolver_create(void);
+void                 adsb_amd_resolver_destroy(adsb_amd_resolver_t* r);
+/* rate_hz == 0 (default): wall clock, as the reference.  Otherwise time = t0_ns + stream sample index / rate_hz. */
+void adsb_amd_resolver_set_sample_clock(adsb_amd_resolver_t* r, int64_t t0_ns, uint32_t rate_hz);
+/*
+ * Applies the reference's sequential rules to sorted records of one scan call and fires the
+ * callback once per accepted frame, in sample order.  `samples_per_buffer` and `nbuffers` describe
+ * the scan call (they advance the stream position used by the sample clock).
+ * Returns the number of accepted frames (>= 0) or a negative error.
+ */
+long adsb_amd_resolver_feed(adsb_amd_resolver_t* r, const adsb_amd_record_t* records, size_t n, size_t samples_per_buffer,
+                            size_t nbuffers, adsb_amd_on_changed_fn cb, void* user);
+size_t adsb_amd_resolver_aircraft_count(const adsb_amd_resolver_t* r);
+
+/* ---------------------------------------------------------------- both: one HandleData-shaped call */
+typedef struct adsb_amd_handler adsb_amd_handler_t;
+
+int         adsb_amd_handler_create(adsb_amd_handler_t** out, int device);
+void        adsb_amd_handler_destroy(adsb_amd_handler_t* h);
+const char* adsb_amd_handler_last_error(const adsb_amd_handler_t* h);
+void        adsb_amd_handler_set_sample_clock(adsb_amd_handler_t* h, int64_t t0_ns, uint32_t rate_hz);
+/* RTLSDR::IDataHandler::HandleData: synchronous; callbacks fire before it returns, in sample order.
+ * buffer_bytes as in adsb_amd_scan_1090 (0 = the reference's behaviour: one call, one buffer). */
+long adsb_amd_handler_handle_data(adsb_amd_handler_t* h, const uint8_t* iq_host, size_t nbytes, size_t buffer_bytes,
+                                  adsb_amd_on_changed_fn cb, void* user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADSB_AMD_H */

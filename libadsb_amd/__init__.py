@@ -1,0 +1,214 @@
+"""libadsb_amd -- MI355X-native 1090ES IQ -> Mode S demodulator behind libadsb's handler surface.
+
+This package is a thin ctypes view of libadsb_amd.so (include/adsb_amd.h).  The demodulation runs in
+hand-written gfx950 HIP kernels; there is no Python or CPU fallback: if the shared library is missing,
+or no HIP device is usable, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadsb_amd.so")
+
+REF_BUFFER_BYTES = 262144
+F_PASS2, F_PHASE, F_NEEDS_ICAO = 1, 2, 4
+
+RECORD_DTYPE = np.dtype([("buffer", "<u4"), ("offset", "<u4"), ("addr", "<u4"), ("delta", "<u2"), ("nbits", "u1"),
+                         ("errorbit", "i1"), ("df", "u1"), ("flags", "u1"), ("msg", "u1", (14,))])
+FRAME_DTYPE = np.dtype([("offset", "<u8"), ("msg", "u1", (14,)), ("nbits", "u1"), ("errorbit", "i1"), ("pass", "u1"),
+                        ("phase_applied", "u1"), ("df", "u1"), ("reserved", "u1"), ("addr", "<u4")])
+AIRCRAFT_DTYPE = np.dtype([("addr", "<u4"), ("callsign", "S8"), ("lat1e7", "<i4"), ("lon1e7", "<i4"), ("altitude", "<i4"),
+                           ("speed", "<u4"), ("track", "<u4"), ("vert_rate", "<i4"), ("squawk", "<u4")])
+assert RECORD_DTYPE.itemsize == 32 and FRAME_DTYPE.itemsize == 32 and AIRCRAFT_DTYPE.itemsize == 40
+
+ON_CHANGED = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
+
+EXPORTS = [
+    "adsb_amd_version", "adsb_amd_create", "adsb_amd_destroy", "adsb_amd_last_error", "adsb_amd_scan_1090",
+    "adsb_amd_scan_1090_submit", "adsb_amd_scan_1090_fetch", "adsb_amd_scan_1090_timing", "adsb_amd_magnitude_1090",
+    "adsb_amd_resolver_create", "adsb_amd_resolver_destroy", "adsb_amd_resolver_set_sample_clock", "adsb_amd_resolver_feed",
+    "adsb_amd_resolver_aircraft_count", "adsb_amd_handler_create", "adsb_amd_handler_destroy", "adsb_amd_handler_last_error",
+    "adsb_amd_handler_set_sample_clock", "adsb_amd_handler_handle_data",
+]
+
+
+class AdsbAmdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libadsb_amd.so (never builds, never falls back)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AdsbAmdError("%s is missing: run `python -m libadsb_amd.build` (needs hipcc); there is no fallback path" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.adsb_amd_version.restype = C.c_char_p
+        L.adsb_amd_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.adsb_amd_destroy.argtypes = [C.c_void_p]
+        L.adsb_amd_last_error.argtypes = [C.c_void_p]
+        L.adsb_amd_last_error.restype = C.c_char_p
+        L.adsb_amd_scan_1090.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.adsb_amd_scan_1090_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
+        L.adsb_amd_scan_1090_fetch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.adsb_amd_scan_1090_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.adsb_amd_magnitude_1090.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.adsb_amd_resolver_create.restype = C.c_void_p
+        L.adsb_amd_resolver_destroy.argtypes = [C.c_void_p]
+        L.adsb_amd_resolver_set_sample_clock.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
+        L.adsb_amd_resolver_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.adsb_amd_resolver_feed.restype = C.c_long
+        L.adsb_amd_resolver_aircraft_count.argtypes = [C.c_void_p]
+        L.adsb_amd_resolver_aircraft_count.restype = C.c_size_t
+        L.adsb_amd_handler_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.adsb_amd_handler_destroy.argtypes = [C.c_void_p]
+        L.adsb_amd_handler_last_error.argtypes = [C.c_void_p]
+        L.adsb_amd_handler_last_error.restype = C.c_char_p
+        L.adsb_amd_handler_set_sample_clock.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
+        L.adsb_amd_handler_handle_data.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.adsb_amd_handler_handle_data.restype = C.c_long
+        _lib = L
+    return _lib
+
+
+class _Collector:
+    """Turns the C callback stream into two structured arrays."""
+
+    def __init__(self):
+        self.frames, self.aircraft = [], []
+        self.cb = ON_CHANGED(self._on)
+
+    def _on(self, _user, frame, aircraft):
+        self.frames.append(C.string_at(frame, 32))
+        self.aircraft.append(C.string_at(aircraft, 40))
+
+    def arrays(self):
+        fr = np.frombuffer(b"".join(self.frames), dtype=FRAME_DTYPE) if self.frames else np.zeros(0, FRAME_DTYPE)
+        ac = np.frombuffer(b"".join(self.aircraft), dtype=AIRCRAFT_DTYPE) if self.aircraft else np.zeros(0, AIRCRAFT_DTYPE)
+        return fr, ac
+
+
+class Scanner:
+    """GPU half: u8 IQ -> sorted candidate records (adsb_amd_ctx_t)."""
+
+    def __init__(self, device=-1):
+        self._l = lib()
+        h = C.c_void_p()
+        rc = self._l.adsb_amd_create(C.byref(h), device)
+        if rc != 0:
+            raise AdsbAmdError("adsb_amd_create failed (%d): %s" % (rc, self._l.adsb_amd_last_error(None).decode()))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.adsb_amd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AdsbAmdError("libadsb_amd error %d: %s" % (rc, self._l.adsb_amd_last_error(self._h).decode()))
+
+    def scan(self, iq, buffer_bytes=0):
+        """Synchronous scan of a host uint8 array; returns a RECORD_DTYPE array."""
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        cap = max(1024, iq.size // 64)
+        while True:
+            out = np.empty(cap, dtype=RECORD_DTYPE)
+            n = C.c_size_t(0)
+            rc = self._l.adsb_amd_scan_1090(self._h, iq.ctypes.data, iq.size, buffer_bytes, out.ctypes.data, cap, C.byref(n))
+            if rc == -4:
+                cap = int(n.value)
+                continue
+            self._check(rc)
+            return out[:n.value].copy()
+
+    def submit(self, device_ptr, nbytes, buffer_bytes=REF_BUFFER_BYTES, stream=0, slot=0):
+        self._check(self._l.adsb_amd_scan_1090_submit(self._h, C.c_void_p(device_ptr), nbytes, buffer_bytes, C.c_void_p(stream), slot))
+
+    def fetch(self, slot=0, copy=True):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._l.adsb_amd_scan_1090_fetch(self._h, slot, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, RECORD_DTYPE)
+        buf = (C.c_uint8 * (n.value * 32)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=RECORD_DTYPE)
+        return arr.copy() if copy else arr
+
+    def timing(self, slot=0):
+        a, b = C.c_float(), C.c_float()
+        self._check(self._l.adsb_amd_scan_1090_timing(self._h, slot, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def magnitude(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        out = np.empty(iq.size // 2, dtype=np.uint16)
+        self._check(self._l.adsb_amd_magnitude_1090(self._h, iq.ctypes.data, iq.size, out.ctypes.data))
+        return out
+
+
+class Resolver:
+    """Host half: records -> accepted frames + aircraft snapshots (adsb_amd_resolver_t).  Needs no GPU."""
+
+    def __init__(self, sample_clock_hz=2000000, t0_ns=1_600_000_000 * 10**9):
+        self._l = lib()
+        self._h = C.c_void_p(self._l.adsb_amd_resolver_create())
+        self._l.adsb_amd_resolver_set_sample_clock(self._h, t0_ns, sample_clock_hz)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.adsb_amd_resolver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def feed(self, records, samples_per_buffer, nbuffers, collect=True):
+        records = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+        col = _Collector()
+        n = self._l.adsb_amd_resolver_feed(self._h, records.ctypes.data, records.size, samples_per_buffer, nbuffers,
+                                           C.cast(col.cb, C.c_void_p) if collect else None, None)
+        if n < 0:
+            raise AdsbAmdError("resolver_feed failed (%d)" % n)
+        fr, ac = col.arrays()
+        return n, fr, ac
+
+    def aircraft_count(self):
+        return self._l.adsb_amd_resolver_aircraft_count(self._h)
+
+
+class Handler1090:
+    """The reference's ADSB1090Handler surface (RTLSDR::IDataHandler::HandleData) over the GPU path."""
+
+    def __init__(self, device=-1, sample_clock_hz=2000000, t0_ns=1_600_000_000 * 10**9):
+        self._l = lib()
+        h = C.c_void_p()
+        rc = self._l.adsb_amd_handler_create(C.byref(h), device)
+        if rc != 0:
+            raise AdsbAmdError("adsb_amd_handler_create failed (%d): %s" % (rc, self._l.adsb_amd_last_error(None).decode()))
+        self._h = h
+        self._l.adsb_amd_handler_set_sample_clock(self._h, t0_ns, sample_clock_hz)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.adsb_amd_handler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def handle_data(self, iq, buffer_bytes=0):
+        """HandleData(span<const u8>): returns (frames, aircraft), one row per OnChanged callback, in callback order."""
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        col = _Collector()
+        n = self._l.adsb_amd_handler_handle_data(self._h, iq.ctypes.data, iq.size, buffer_bytes, C.cast(col.cb, C.c_void_p), None)
+        if n < 0:
+            raise AdsbAmdError("handle_data failed (%d): %s" % (n, self._l.adsb_amd_handler_last_error(self._h).decode()))
+        return col.arrays()

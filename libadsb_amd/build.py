@@ -1,0 +1,55 @@
+"""Build the native libraries in-tree (they travel to the GPU box with the snapshot).
+
+    python -m libadsb_amd.build            # everything
+    python -m libadsb_amd.build --force
+
+hipcc cross-compiles gfx950 code objects without a GPU.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+
+LIB = os.path.join(HERE, "libadsb_amd.so")
+SYNTH = os.path.join(HERE, "libadsb_synth.so")
+
+HIP_SOURCES = ["scan1090.hip", "capi.cpp", "resolver1090.cpp"]
+HIP_DEPS = HIP_SOURCES + ["scan1090.h", "resolver1090.hpp", os.path.join(ROOT, "include", "adsb_amd.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d if os.path.isabs(d) else os.path.join(CSRC, d)) > t for d in deps)
+
+
+def build_hip(force=False, verbose=False):
+    if not force and not _stale(LIB, HIP_DEPS):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_synth(force=False):
+    src = os.path.join(CSRC, "synth1090.c")
+    if not force and not _stale(SYNTH, [src, os.path.join(CSRC, "synth1090.h")]):
+        return SYNTH
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-pthread", "-o", SYNTH, src, "-lm"])
+    return SYNTH
+
+
+def build_all(force=False, verbose=False):
+    return build_hip(force, verbose), build_synth(force)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

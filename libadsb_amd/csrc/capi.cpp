@@ -1,0 +1,454 @@
+// capi.cpp -- C ABI of libadsb_amd.so (include/adsb_amd.h): GPU context, two-slot scan pipeline, handler.
+// Host-side only; the kernels live in scan1090.hip.  There is deliberately no CPU demodulation path here:
+// every entry point that needs the device fails with ADSB_AMD_ENODEV / ADSB_AMD_EHIP when HIP is unusable.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "adsb_amd.h"
+#include "resolver1090.hpp"
+#include "scan1090.h"
+
+using namespace adsb_amd;
+
+namespace
+{
+thread_local std::string g_create_error;
+
+struct Slot
+{
+    uint32_t*          counts   = nullptr; // per chunk
+    uint32_t*          offsets  = nullptr;
+    adsb_amd_record_t* regions  = nullptr; // total_chunks * cap
+    adsb_amd_record_t* dense    = nullptr;
+    uint32_t*          total_d  = nullptr; // device {total, overflow}
+    uint32_t*          total_h  = nullptr; // pinned {total, overflow}
+    adsb_amd_record_t* host     = nullptr; // pinned result
+    size_t             host_cap = 0;       // records
+    size_t             chunks_cap = 0, cap_per_chunk = 0;
+    hipEvent_t         ev_begin = nullptr, ev_scan0 = nullptr, ev_scan1 = nullptr, ev_done = nullptr;
+    bool               pending = false, timed = false;
+    // the submitted job (needed again when a chunk region overflows and the scan is repeated with a larger cap)
+    ScanArgs    args{};
+    hipStream_t stream   = nullptr;
+    size_t      nrecords = 0;
+    float       scan_ms = 0.f, total_ms = 0.f;
+};
+} // namespace
+
+struct adsb_amd_ctx
+{
+    int         device = 0;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    uint16_t*   lut     = nullptr;
+    uint32_t*   crc_tab = nullptr;
+    uint16_t*   lut978  = nullptr;
+    uint8_t*    staging = nullptr; // device copy of host input
+    size_t      staging_cap = 0;
+    Slot        slot[2];
+    std::string error;
+};
+
+namespace
+{
+#define HIP_TRY(ctx, expr)                                                                              \
+    do                                                                                                  \
+    {                                                                                                   \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+        {                                                                                               \
+            (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(_e);                           \
+            return ADSB_AMD_EHIP;                                                                       \
+        }                                                                                               \
+    } while (0)
+
+int fail(adsb_amd_ctx* c, int code, const char* msg)
+{
+    c->error = msg;
+    return code;
+}
+
+constexpr uint32_t kDefaultCap = 32;
+
+void free_slot(Slot& s)
+{
+    if (s.counts) (void)hipFree(s.counts);
+    if (s.offsets) (void)hipFree(s.offsets);
+    if (s.regions) (void)hipFree(s.regions);
+    if (s.dense) (void)hipFree(s.dense);
+    s.counts = s.offsets = nullptr;
+    s.regions = s.dense = nullptr;
+    s.chunks_cap = s.cap_per_chunk = 0;
+}
+
+int ensure_slot(adsb_amd_ctx* c, Slot& s, size_t chunks, size_t cap)
+{
+    if (chunks <= s.chunks_cap && cap == s.cap_per_chunk) return ADSB_AMD_OK;
+    free_slot(s);
+    size_t nch = chunks ? chunks : 1;
+    HIP_TRY(c, hipMalloc(&s.counts, nch * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&s.offsets, nch * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&s.regions, nch * cap * sizeof(adsb_amd_record_t)));
+    HIP_TRY(c, hipMalloc(&s.dense, nch * cap * sizeof(adsb_amd_record_t)));
+    s.chunks_cap    = nch;
+    s.cap_per_chunk = cap;
+    return ADSB_AMD_OK;
+}
+
+int ensure_host(adsb_amd_ctx* c, Slot& s, size_t nrec)
+{
+    if (nrec <= s.host_cap) return ADSB_AMD_OK;
+    if (s.host) (void)hipHostFree(s.host);
+    s.host      = nullptr;
+    s.host_cap  = 0;
+    size_t want = nrec + nrec / 4 + 1024;
+    HIP_TRY(c, hipHostMalloc(&s.host, want * sizeof(adsb_amd_record_t), hipHostMallocDefault));
+    s.host_cap = want;
+    return ADSB_AMD_OK;
+}
+
+// Describe one scan call.  buffer_bytes == 0: one buffer spanning the whole input.
+int make_args(adsb_amd_ctx* c, const void* iq_device, size_t nbytes, size_t buffer_bytes, ScanArgs* a)
+{
+    if (((uintptr_t)iq_device & 15u) != 0) return fail(c, ADSB_AMD_EINVAL, "iq_device must be 16-byte aligned");
+    size_t bb   = buffer_bytes ? buffer_bytes : (nbytes & ~(size_t)1);
+    size_t nbuf = bb ? nbytes / bb : 0;
+    if (buffer_bytes == 0 && nbytes < 480) nbuf = 0; // the reference underflows its loop bound below 480 bytes; we decline
+    if (bb & 1u) return fail(c, ADSB_AMD_EINVAL, "buffer_bytes must be even");
+    if (nbuf > 1 && (bb & 15u) != 0) return fail(c, ADSB_AMD_EINVAL, "buffer_bytes must be a multiple of 16 when the input holds several buffers");
+    if (nbuf > 0 && bb < 480) return fail(c, ADSB_AMD_EINVAL, "each buffer needs at least 480 bytes (240 samples)");
+    if (bb / 2 > 0xFFFFFF00ull) return fail(c, ADSB_AMD_EINVAL, "buffer too large (sample index must fit 32 bits)");
+    std::memset(a, 0, sizeof(*a));
+    a->iq             = static_cast<const uint8_t*>(iq_device);
+    a->buf_stride     = bb;
+    a->buf_samples    = (uint32_t)(bb / 2);
+    a->nbuf           = (uint32_t)nbuf;
+    a->chunks_per_buf = chunks_per_buffer(a->buf_samples);
+    uint64_t total    = (uint64_t)a->chunks_per_buf * nbuf;
+    if (total > 0x7FFFFFFFull) return fail(c, ADSB_AMD_EINVAL, "input too large for one scan call");
+    a->total_chunks = (uint32_t)total;
+    a->lut          = c->lut;
+    a->crc_tab      = c->crc_tab;
+    return ADSB_AMD_OK;
+}
+
+int enqueue(adsb_amd_ctx* c, Slot& s)
+{
+    s.args.chunk_records = s.regions;
+    s.args.chunk_counts  = s.counts;
+    s.args.cap           = (uint32_t)s.cap_per_chunk;
+    HIP_TRY(c, hipEventRecord(s.ev_begin, s.stream));
+    HIP_TRY(c, launch_scan1090(s.args, s.dense, s.offsets, s.total_d, s.stream, s.ev_scan0, s.ev_scan1));
+    HIP_TRY(c, hipMemcpyAsync(s.total_h, s.total_d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(c, hipEventRecord(s.ev_done, s.stream));
+    return ADSB_AMD_OK;
+}
+} // namespace
+
+extern "C" const char* adsb_amd_version(void) { return "libadsb_amd 0.1 (gfx950)"; }
+
+extern "C" int adsb_amd_create(adsb_amd_ctx_t** out, int device)
+{
+    if (!out) return ADSB_AMD_EINVAL;
+    *out      = nullptr;
+    int ndev  = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+    {
+        g_create_error = std::string("no usable HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0")
+                         + " (libadsb_amd has no CPU demodulation path)";
+        return ADSB_AMD_ENODEV;
+    }
+    if (device < 0)
+    {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= ndev)
+    {
+        g_create_error = "device index out of range";
+        return ADSB_AMD_EINVAL;
+    }
+    adsb_amd_ctx* c = new (std::nothrow) adsb_amd_ctx();
+    if (!c) return ADSB_AMD_EHIP;
+    c->device = device;
+    auto bail = [&](const char* what, hipError_t err) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        adsb_amd_destroy(c);
+        return ADSB_AMD_ENODEV;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+
+    std::vector<uint16_t> lut(kLutSize);
+    build_mag_lut(lut.data());
+    uint32_t tab[112];
+    build_crc_table(tab);
+    if ((e = hipMalloc(&c->lut, kLutSize * sizeof(uint16_t))) != hipSuccess) return bail("hipMalloc(lut)", e);
+    if ((e = hipMalloc(&c->crc_tab, sizeof(tab))) != hipSuccess) return bail("hipMalloc(crc)", e);
+    if ((e = hipMemcpy(c->lut, lut.data(), kLutSize * sizeof(uint16_t), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(lut)", e);
+    if ((e = hipMemcpy(c->crc_tab, tab, sizeof(tab), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(crc)", e);
+    for (Slot& s : c->slot)
+    {
+        if ((e = hipMalloc(&s.total_d, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(total)", e);
+        if ((e = hipHostMalloc(&s.total_h, 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(total)", e);
+        if ((e = hipEventCreate(&s.ev_begin)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreate(&s.ev_scan0)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreate(&s.ev_scan1)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreate(&s.ev_done)) != hipSuccess) return bail("hipEventCreate", e);
+    }
+    *out = c;
+    return ADSB_AMD_OK;
+}
+
+extern "C" void adsb_amd_destroy(adsb_amd_ctx_t* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (Slot& s : c->slot)
+    {
+        free_slot(s);
+        if (s.total_d) (void)hipFree(s.total_d);
+        if (s.total_h) (void)hipHostFree(s.total_h);
+        if (s.host) (void)hipHostFree(s.host);
+        if (s.ev_begin) (void)hipEventDestroy(s.ev_begin);
+        if (s.ev_scan0) (void)hipEventDestroy(s.ev_scan0);
+        if (s.ev_scan1) (void)hipEventDestroy(s.ev_scan1);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+    }
+    if (c->lut) (void)hipFree(c->lut);
+    if (c->crc_tab) (void)hipFree(c->crc_tab);
+    if (c->lut978) (void)hipFree(c->lut978);
+    if (c->staging) (void)hipFree(c->staging);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    delete c;
+}
+
+extern "C" const char* adsb_amd_last_error(const adsb_amd_ctx_t* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+extern "C" int adsb_amd_scan_1090_submit(adsb_amd_ctx_t* c, const void* iq_device, size_t nbytes, size_t buffer_bytes, void* hip_stream,
+                                         int slot)
+{
+    if (!c) return ADSB_AMD_EINVAL;
+    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    Slot& s = c->slot[slot];
+    if (s.pending) return fail(c, ADSB_AMD_ESTATE, "slot still has an unfetched scan");
+    HIP_TRY(c, hipSetDevice(c->device));
+    ScanArgs a;
+    int      rc = make_args(c, iq_device, nbytes, buffer_bytes, &a);
+    if (rc) return rc;
+    size_t cap = s.cap_per_chunk ? s.cap_per_chunk : kDefaultCap;
+    if ((rc = ensure_slot(c, s, a.total_chunks, cap))) return rc;
+    s.args   = a;
+    s.stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    if ((rc = enqueue(c, s))) return rc;
+    s.pending = true;
+    return ADSB_AMD_OK;
+}
+
+extern "C" int adsb_amd_scan_1090_fetch(adsb_amd_ctx_t* c, int slot, const adsb_amd_record_t** records, size_t* n)
+{
+    if (!c) return ADSB_AMD_EINVAL;
+    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    Slot& s = c->slot[slot];
+    if (!s.pending) return fail(c, ADSB_AMD_ESTATE, "fetch without submit");
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (;;)
+    {
+        HIP_TRY(c, hipEventSynchronize(s.ev_done));
+        if (s.total_h[1] == 0) break;
+        // A chunk produced more records than its region holds (dense noise, adversarial input): repeat with regions
+        // eight times larger, up to the hard bound of two records per preamble position.
+        size_t cap = s.cap_per_chunk * 8;
+        if (cap > (size_t)2 * kChunk) cap = (size_t)2 * kChunk;
+        if (cap == s.cap_per_chunk)
+        {
+            s.pending = false;
+            return fail(c, ADSB_AMD_EHIP, "record overflow at the maximum region size (internal error)");
+        }
+        int rc = ensure_slot(c, s, s.args.total_chunks, cap);
+        if (rc == ADSB_AMD_OK) rc = enqueue(c, s);
+        if (rc)
+        {
+            s.pending = false;
+            return rc;
+        }
+    }
+    s.nrecords = s.total_h[0];
+    int rc     = ensure_host(c, s, s.nrecords);
+    if (rc)
+    {
+        s.pending = false;
+        return rc;
+    }
+    if (s.nrecords)
+    {
+        HIP_TRY(c, hipMemcpyAsync(s.host, s.dense, s.nrecords * sizeof(adsb_amd_record_t), hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    }
+    s.pending = false;
+    s.timed   = true;
+    (void)hipEventElapsedTime(&s.scan_ms, s.ev_scan0, s.ev_scan1);
+    (void)hipEventElapsedTime(&s.total_ms, s.ev_begin, s.ev_done);
+    if (records) *records = s.host;
+    if (n) *n = s.nrecords;
+    return ADSB_AMD_OK;
+}
+
+extern "C" int adsb_amd_scan_1090_timing(adsb_amd_ctx_t* c, int slot, float* scan_kernel_ms, float* total_ms)
+{
+    if (!c) return ADSB_AMD_EINVAL;
+    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    Slot& s = c->slot[slot];
+    if (!s.timed) return fail(c, ADSB_AMD_ESTATE, "no completed scan on this slot");
+    if (scan_kernel_ms) *scan_kernel_ms = s.scan_ms;
+    if (total_ms) *total_ms = s.total_ms;
+    return ADSB_AMD_OK;
+}
+
+namespace
+{
+int stage_input(adsb_amd_ctx* c, const uint8_t* iq_host, size_t nbytes)
+{
+    size_t want = nbytes + 64;
+    if (want > c->staging_cap)
+    {
+        if (c->staging) (void)hipFree(c->staging);
+        c->staging     = nullptr;
+        c->staging_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->staging, want));
+        c->staging_cap = want;
+    }
+    if (nbytes) HIP_TRY(c, hipMemcpyAsync(c->staging, iq_host, nbytes, hipMemcpyHostToDevice, c->stream));
+    return ADSB_AMD_OK;
+}
+} // namespace
+
+extern "C" int adsb_amd_scan_1090(adsb_amd_ctx_t* c, const uint8_t* iq_host, size_t nbytes, size_t buffer_bytes, adsb_amd_record_t* out,
+                                  size_t cap, size_t* n_out)
+{
+    if (!c) return ADSB_AMD_EINVAL;
+    if (!iq_host && nbytes) return fail(c, ADSB_AMD_EINVAL, "iq_host is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = stage_input(c, iq_host, nbytes);
+    if (rc) return rc;
+    if ((rc = adsb_amd_scan_1090_submit(c, c->staging, nbytes, buffer_bytes, c->stream, 0))) return rc;
+    const adsb_amd_record_t* rec = nullptr;
+    size_t                   n   = 0;
+    if ((rc = adsb_amd_scan_1090_fetch(c, 0, &rec, &n))) return rc;
+    if (n_out) *n_out = n;
+    if (n > cap) return fail(c, ADSB_AMD_ENOSPC, "output array too small");
+    if (n && out) std::memcpy(out, rec, n * sizeof(adsb_amd_record_t));
+    return ADSB_AMD_OK;
+}
+
+extern "C" int adsb_amd_magnitude_1090(adsb_amd_ctx_t* c, const uint8_t* iq_host, size_t nbytes, uint16_t* mag_out)
+{
+    if (!c) return ADSB_AMD_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t n = nbytes / 2;
+    if (n == 0) return ADSB_AMD_OK;
+    int rc = stage_input(c, iq_host, nbytes);
+    if (rc) return rc;
+    uint16_t* d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, n * sizeof(uint16_t)));
+    hipError_t e = launch_magnitude1090(c->staging, d, n, c->lut, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(mag_out, d, n * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess)
+    {
+        c->error = std::string("magnitude_1090: ") + hipGetErrorString(e);
+        return ADSB_AMD_EHIP;
+    }
+    return ADSB_AMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ handler
+struct adsb_amd_handler
+{
+    adsb_amd_ctx*                  ctx = nullptr;
+    adsb_amd::Resolver1090         resolver;
+    std::vector<adsb_amd_record_t> scratch;
+    std::string                    error;
+};
+
+extern "C" int adsb_amd_handler_create(adsb_amd_handler_t** out, int device)
+{
+    if (!out) return ADSB_AMD_EINVAL;
+    *out                = nullptr;
+    adsb_amd_handler* h = new (std::nothrow) adsb_amd_handler();
+    if (!h) return ADSB_AMD_EHIP;
+    int rc = adsb_amd_create(&h->ctx, device);
+    if (rc)
+    {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return ADSB_AMD_OK;
+}
+
+extern "C" void adsb_amd_handler_destroy(adsb_amd_handler_t* h)
+{
+    if (!h) return;
+    adsb_amd_destroy(h->ctx);
+    delete h;
+}
+
+extern "C" const char* adsb_amd_handler_last_error(const adsb_amd_handler_t* h)
+{
+    if (!h) return adsb_amd_last_error(nullptr);
+    return h->error.empty() ? adsb_amd_last_error(h->ctx) : h->error.c_str();
+}
+
+extern "C" void adsb_amd_handler_set_sample_clock(adsb_amd_handler_t* h, int64_t t0_ns, uint32_t rate_hz)
+{
+    if (h) h->resolver.set_sample_clock(t0_ns, rate_hz);
+}
+
+extern "C" long adsb_amd_handler_handle_data(adsb_amd_handler_t* h, const uint8_t* iq_host, size_t nbytes, size_t buffer_bytes,
+                                             adsb_amd_on_changed_fn cb, void* user)
+{
+    if (!h) return ADSB_AMD_EINVAL;
+    h->error.clear();
+    adsb_amd_ctx* c  = h->ctx;
+    int           rc = stage_input(c, iq_host, nbytes);
+    if (rc) return rc;
+    if ((rc = adsb_amd_scan_1090_submit(c, c->staging, nbytes, buffer_bytes, c->stream, 0))) return rc;
+    const adsb_amd_record_t* rec = nullptr;
+    size_t                   n   = 0;
+    if ((rc = adsb_amd_scan_1090_fetch(c, 0, &rec, &n))) return rc;
+    const ScanArgs& a = c->slot[0].args;
+    // stream position advances by everything the caller handed over, as the reference's HandleData consumes it
+    size_t spb  = a.nbuf ? a.buf_samples : nbytes / 2;
+    size_t nbuf = a.nbuf ? a.nbuf : 1;
+    return h->resolver.feed(rec, n, spb, nbuf, cb, user);
+}
+
+// ------------------------------------------------------------------------------------------------ resolver (host only)
+struct adsb_amd_resolver
+{
+    adsb_amd::Resolver1090 impl;
+};
+
+extern "C" adsb_amd_resolver_t* adsb_amd_resolver_create(void) { return new (std::nothrow) adsb_amd_resolver(); }
+extern "C" void                 adsb_amd_resolver_destroy(adsb_amd_resolver_t* r) { delete r; }
+extern "C" void adsb_amd_resolver_set_sample_clock(adsb_amd_resolver_t* r, int64_t t0_ns, uint32_t rate_hz)
+{
+    if (r) r->impl.set_sample_clock(t0_ns, rate_hz);
+}
+extern "C" long adsb_amd_resolver_feed(adsb_amd_resolver_t* r, const adsb_amd_record_t* records, size_t n, size_t samples_per_buffer,
+                                       size_t nbuffers, adsb_amd_on_changed_fn cb, void* user)
+{
+    if (!r) return ADSB_AMD_EINVAL;
+    return r->impl.feed(records, n, samples_per_buffer, nbuffers, cb, user);
+}
+extern "C" size_t adsb_amd_resolver_aircraft_count(const adsb_amd_resolver_t* r) { return r ? r->impl.aircraft_count() : 0; }

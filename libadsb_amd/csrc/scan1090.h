@@ -1,0 +1,62 @@
+// scan1090.h -- internal launch interface between the C-ABI layer (capi.cpp) and the gfx950 kernels (scan1090.hip).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "adsb_amd.h"
+
+namespace adsb_amd
+{
+
+// Geometry of one work item ("chunk"): one wavefront demodulates kChunk consecutive preamble positions
+// of one reference buffer out of an LDS-staged window of kChunk + kHalo samples.
+constexpr int kLanes      = 64;
+constexpr int kRowSamples = 512; // one 16-byte load per lane = 8 IQ samples per lane = 512 per wavefront
+constexpr int kRows       = 8;
+constexpr int kChunk      = kRows * kRowSamples; // 4096 positions
+constexpr int kHalo       = 256;                 // >= 240 samples read past the last position, half a row
+constexpr int kFront      = 8;                   // u16 slots before the window; slot 7 = sample g0-1
+constexpr int kTileU16    = kFront + kChunk + kHalo + 8;
+constexpr int kFrameSpan  = 240;                 // (8 + 112) * 2 samples: reference loop bound (ADSB1090.cpp:772)
+constexpr int kLutSize    = 32768;               // magnitude LUT indexed by min(i*i+q*q, 32767)
+
+struct ScanArgs
+{
+    const uint8_t*     iq;           // device, 16-byte aligned
+    uint64_t           buf_stride;   // bytes between consecutive reference buffers
+    uint32_t           buf_samples;  // N: samples per reference buffer
+    uint32_t           nbuf;
+    uint32_t           chunks_per_buf;
+    uint32_t           total_chunks;
+    const uint16_t*    lut;          // kLutSize entries
+    const uint32_t*    crc_tab;      // 112 entries (ModesChecksumTable semantics)
+    adsb_amd_record_t* chunk_records; // total_chunks * cap
+    uint32_t*          chunk_counts;  // total_chunks
+    uint32_t           cap;           // records per chunk region
+};
+
+inline uint32_t chunks_per_buffer(uint32_t buf_samples)
+{
+    if (buf_samples <= (uint32_t)kFrameSpan) return 0;
+    uint32_t positions = buf_samples - (uint32_t)kFrameSpan;
+    return (positions + (uint32_t)kChunk - 1) / (uint32_t)kChunk;
+}
+
+// Enqueue: demodulation kernel, then prefix over the per-chunk counts, then the ordered gather into `dense`.
+// `total_and_overflow` is a device uint32_t[2]: {number of records in dense, overflow flag}.
+hipError_t launch_scan1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t* chunk_offsets, uint32_t* total_and_overflow,
+                           hipStream_t stream, hipEvent_t ev_scan_begin, hipEvent_t ev_scan_end);
+
+// magnitudes exactly as the reference computes them (parity helper)
+hipError_t launch_magnitude1090(const uint8_t* iq, uint16_t* mag, size_t nsamples, const uint16_t* lut, hipStream_t stream);
+
+// UAT978 phase LUT map (UAT978.cpp:52): phi[k] = lut[I | Q<<8]
+hipError_t launch_phase978(const uint8_t* iq, uint16_t* phi, size_t nsamples, const uint16_t* lut65536, hipStream_t stream);
+
+// host-side table builders (exact integer / polynomial arithmetic, no reference text)
+void build_mag_lut(uint16_t* lut /* kLutSize */);
+void build_crc_table(uint32_t* tab /* 112 */);
+
+} // namespace adsb_amd

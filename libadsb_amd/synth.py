@@ -1,0 +1,75 @@
+"""Deterministic synthetic 1090ES u8 IQ -- ctypes view of libadsb_synth.so."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libadsb_synth.so")
+_SRC = os.path.join(_HERE, "csrc", "synth1090.c")
+
+BUFFER_BYTES = 262144  # RTLSDR::BufferLength (reference RTLSDR.hpp:55)
+
+
+class SynthCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("noise_amp", C.c_int32), ("mean_spacing", C.c_int32), ("amp_lo", C.c_int32),
+                ("amp_hi", C.c_int32), ("pct_df17", C.c_int32), ("pct_df11", C.c_int32), ("pct_bitflip", C.c_int32),
+                ("pct_halfsample", C.c_int32), ("pool_size", C.c_int32)]
+
+
+FRAME_DTYPE = np.dtype([("start", "<u4"), ("msg", "u1", (14,)), ("nbits", "u1"), ("flipped_bit", "i1"),
+                        ("half_sample", "u1"), ("amplitude", "u1")])
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(_SRC):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-pthread", "-o", _LIB_PATH, _SRC, "-lm"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.adsb_synth_default.argtypes = [C.POINTER(SynthCfg)]
+        L.adsb_synth_fill.argtypes = [C.POINTER(SynthCfg), C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.adsb_synth_fill_range.argtypes = [C.POINTER(SynthCfg), C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int]
+        L.adsb_synth_fill_range.restype = C.c_long
+        L.adsb_synth_pool_addr.argtypes = [C.POINTER(SynthCfg), C.c_uint32]
+        L.adsb_synth_pool_addr.restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+def default_cfg(**over):
+    c = SynthCfg()
+    lib().adsb_synth_default(C.byref(c))
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def fill(buf_index, nbytes=BUFFER_BYTES, cfg=None, manifest=False):
+    cfg = cfg or default_cfg()
+    out = np.empty(nbytes, dtype=np.uint8)
+    if manifest:
+        fr = np.zeros(4096, dtype=FRAME_DTYPE)
+        n = lib().adsb_synth_fill(C.byref(cfg), buf_index, out.ctypes.data, nbytes, fr.ctypes.data, fr.size)
+        return out, fr[:min(n, fr.size)]
+    lib().adsb_synth_fill(C.byref(cfg), buf_index, out.ctypes.data, nbytes, None, 0)
+    return out
+
+
+def fill_range(first_buf, nbuf, buf_bytes=BUFFER_BYTES, cfg=None, nthreads=None, out=None):
+    """Returns (uint8 array of nbuf*buf_bytes, frames injected)."""
+    cfg = cfg or default_cfg()
+    if out is None:
+        out = np.empty(nbuf * buf_bytes, dtype=np.uint8)
+    nthreads = nthreads or min(32, os.cpu_count() or 1)
+    n = lib().adsb_synth_fill_range(C.byref(cfg), first_buf, nbuf, out.ctypes.data, buf_bytes, nthreads)
+    return out, n

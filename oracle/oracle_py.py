@@ -1,0 +1,160 @@
+"""ctypes view of the CPU oracle (oracle/liboracle1090.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (libadsb_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle1090.so")
+
+
+class Frame(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("msg", C.c_uint8 * 14), ("nbits", C.c_uint8), ("errorbit", C.c_int8),
+                ("pass_", C.c_uint8), ("phase_applied", C.c_uint8), ("df", C.c_uint8), ("reserved", C.c_uint8),
+                ("addr", C.c_uint32)]
+
+
+class Aircraft(C.Structure):
+    _fields_ = [("addr", C.c_uint32), ("callsign", C.c_char * 8), ("lat1e7", C.c_int32), ("lon1e7", C.c_int32),
+                ("altitude", C.c_int32), ("speed", C.c_uint32), ("track", C.c_uint32), ("vert_rate", C.c_int32),
+                ("squawk", C.c_uint32)]
+
+
+class Probe(C.Structure):
+    _fields_ = [("stage1", C.c_uint8), ("stage2", C.c_uint8), ("p_errors", C.c_uint8 * 2), ("p_energy_ok", C.c_uint8 * 2),
+                ("p_msg", (C.c_uint8 * 14) * 2), ("p_df", C.c_uint8 * 2), ("p_nbits", C.c_uint8 * 2),
+                ("phase_applied", C.c_uint8), ("p_crc_state", C.c_uint8 * 2), ("p_errorbit", C.c_int8 * 2),
+                ("p_fixed", (C.c_uint8 * 14) * 2), ("p_ap_addr", C.c_uint32 * 2), ("p_delta", C.c_uint32 * 2)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "stage1_pass", "stage2_pass", "sliced", "energy_pass", "decoded",
+                                          "accepted", "retries", "phase_applied")]
+
+
+CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Frame), C.POINTER(Aircraft))
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "oracle1090.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle1090.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.oracle1090_create.restype = C.c_void_p
+        L.oracle1090_destroy.argtypes = [C.c_void_p]
+        L.oracle1090_set_sample_clock.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
+        L.oracle1090_handle_data.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.oracle1090_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.oracle1090_aircraft_count.argtypes = [C.c_void_p]
+        L.oracle1090_aircraft_count.restype = C.c_size_t
+        L.oracle1090_mag_lut.restype = C.POINTER(C.c_uint16)
+        L.oracle1090_magnitude.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.oracle1090_checksum_entry.argtypes = [C.c_int]
+        L.oracle1090_checksum_entry.restype = C.c_uint32
+        L.oracle1090_checksum.argtypes = [C.c_void_p, C.c_int]
+        L.oracle1090_checksum.restype = C.c_uint32
+        L.oracle1090_fix_single_bit.argtypes = [C.c_void_p, C.c_int]
+        L.oracle1090_msglen_bits.argtypes = [C.c_int]
+        L.oracle1090_probe_at.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(Probe)]
+        L.oracle1090_gate_offsets.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.oracle1090_gate_offsets.restype = C.c_size_t
+        L.oracle1090_cpr_nl.argtypes = [C.c_double]
+        L.oracle1090_decode_cpr.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.oracle978_phase_lut.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+FRAME_DTYPE = np.dtype([("offset", "<u8"), ("msg", "u1", (14,)), ("nbits", "u1"), ("errorbit", "i1"), ("pass", "u1"),
+                        ("phase_applied", "u1"), ("df", "u1"), ("reserved", "u1"), ("addr", "<u4")])
+AIRCRAFT_DTYPE = np.dtype([("addr", "<u4"), ("callsign", "S8"), ("lat1e7", "<i4"), ("lon1e7", "<i4"), ("altitude", "<i4"),
+                           ("speed", "<u4"), ("track", "<u4"), ("vert_rate", "<i4"), ("squawk", "<u4")])
+
+
+def format_aircraft(addr, callsign, lat1e7, lon1e7, altitude, speed, squawk=0):
+    """The reference test's callback line (tests/test_1090.cpp:19-28):
+    "{:x}[{: >8}]: Pos={:+03.2f}:{:+03.2f}^{:05} Speed={:03} Count={}" (Count prints the squawk)."""
+    if isinstance(callsign, (bytes, bytearray)):
+        cs = bytes(callsign).ljust(8, b"\0").decode("latin-1")
+    else:
+        cs = str(callsign)
+    return "%x[%s]: Pos=%s:%s^%s Speed=%03d Count=%d" % (
+        addr, cs.rjust(8), "%+03.2f" % (lat1e7 / 10000000.0), "%+03.2f" % (lon1e7 / 10000000.0),
+        ("%05d" % altitude), speed, squawk)
+
+
+class Oracle1090:
+    """One reference handler instance (ICAO cache + aircraft table persist across handle_data calls)."""
+
+    def __init__(self, sample_clock_hz=2000000, t0_ns=1_600_000_000 * 10**9):
+        self._l = lib()
+        self._h = C.c_void_p(self._l.oracle1090_create())
+        self._l.oracle1090_set_sample_clock(self._h, t0_ns, sample_clock_hz)
+
+    def close(self):
+        if self._h:
+            self._l.oracle1090_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def handle_data(self, iq, collect=True):
+        """iq: contiguous uint8 array. Returns (frames, aircraft) structured arrays (one row per accepted frame)."""
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        frames, crafts = [], []
+        if collect:
+            def _cb(_u, f, a):
+                frames.append(bytes(memoryview(f.contents).cast("B")[:C.sizeof(Frame)]))
+                crafts.append(bytes(memoryview(a.contents).cast("B")[:C.sizeof(Aircraft)]))
+            cb = CB(_cb)
+            self._l.oracle1090_handle_data(self._h, iq.ctypes.data, iq.size, cb, None)
+        else:
+            self._l.oracle1090_handle_data(self._h, iq.ctypes.data, iq.size, None, None)
+        fr = np.frombuffer(b"".join(frames), dtype=FRAME_DTYPE) if frames else np.zeros(0, FRAME_DTYPE)
+        ac = np.frombuffer(b"".join(crafts), dtype=AIRCRAFT_DTYPE) if crafts else np.zeros(0, AIRCRAFT_DTYPE)
+        return fr, ac
+
+    def stats(self):
+        s = Stats()
+        self._l.oracle1090_get_stats(self._h, C.byref(s))
+        return {n: getattr(s, n) for n, _ in Stats._fields_}
+
+
+def magnitude(iq):
+    iq = np.ascontiguousarray(iq, dtype=np.uint8)
+    m = np.empty(iq.size // 2, dtype=np.uint16)
+    lib().oracle1090_magnitude(iq.ctypes.data, iq.size, m.ctypes.data)
+    return m
+
+
+def probe_at(mag, j):
+    p = Probe()
+    lib().oracle1090_probe_at(mag.ctypes.data, mag.size, j, C.byref(p))
+    return p
+
+
+def gate_offsets(mag):
+    """All offsets passing both preamble gates (state-free)."""
+    cap = max(1024, mag.size // 16)
+    out = np.empty(cap, dtype=np.uint32)
+    n = lib().oracle1090_gate_offsets(mag.ctypes.data, mag.size, out.ctypes.data, cap)
+    if n > cap:
+        out = np.empty(n, dtype=np.uint32)
+        n = lib().oracle1090_gate_offsets(mag.ctypes.data, mag.size, out.ctypes.data, n)
+    return out[:n].copy()
