@@ -45,6 +45,12 @@ def lib():
     """Load libadsb_amd.so (never builds, never falls back)."""
     global _lib
     if _lib is None:
+        # When PyTorch shares the process it must initialise its bundled HIP runtime first: both runtimes carry the
+        # SONAME libamdhip64.so.7, and torch cannot find a device once the system runtime has been loaded before it.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise AdsbAmdError("%s is missing: run `python -m libadsb_amd.build` (needs hipcc); there is no fallback path" % LIB_PATH)
         L = C.CDLL(LIB_PATH)

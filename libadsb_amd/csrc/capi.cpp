@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -23,6 +24,7 @@ struct Slot
 {
     uint32_t*          counts   = nullptr; // per chunk
     uint32_t*          offsets  = nullptr;
+    uint32_t*          block_sums = nullptr; // one per 1024 chunks
     adsb_amd_record_t* regions  = nullptr; // total_chunks * cap
     adsb_amd_record_t* dense    = nullptr;
     uint32_t*          total_d  = nullptr; // device {total, overflow}
@@ -44,7 +46,6 @@ struct adsb_amd_ctx
 {
     int         device = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr;
-    uint16_t*   lut     = nullptr;
     uint32_t*   crc_tab = nullptr;
     uint16_t*   lut978  = nullptr;
     uint8_t*    staging = nullptr; // device copy of host input
@@ -78,9 +79,10 @@ void free_slot(Slot& s)
 {
     if (s.counts) (void)hipFree(s.counts);
     if (s.offsets) (void)hipFree(s.offsets);
+    if (s.block_sums) (void)hipFree(s.block_sums);
     if (s.regions) (void)hipFree(s.regions);
     if (s.dense) (void)hipFree(s.dense);
-    s.counts = s.offsets = nullptr;
+    s.counts = s.offsets = s.block_sums = nullptr;
     s.regions = s.dense = nullptr;
     s.chunks_cap = s.cap_per_chunk = 0;
 }
@@ -92,6 +94,7 @@ int ensure_slot(adsb_amd_ctx* c, Slot& s, size_t chunks, size_t cap)
     size_t nch = chunks ? chunks : 1;
     HIP_TRY(c, hipMalloc(&s.counts, nch * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc(&s.offsets, nch * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&s.block_sums, ((nch + 1023) / 1024) * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc(&s.regions, nch * cap * sizeof(adsb_amd_record_t)));
     HIP_TRY(c, hipMalloc(&s.dense, nch * cap * sizeof(adsb_amd_record_t)));
     s.chunks_cap    = nch;
@@ -131,8 +134,8 @@ int make_args(adsb_amd_ctx* c, const void* iq_device, size_t nbytes, size_t buff
     uint64_t total    = (uint64_t)a->chunks_per_buf * nbuf;
     if (total > 0x7FFFFFFFull) return fail(c, ADSB_AMD_EINVAL, "input too large for one scan call");
     a->total_chunks = (uint32_t)total;
-    a->lut          = c->lut;
     a->crc_tab      = c->crc_tab;
+    if (const char* pl = std::getenv("ADSB_AMD_PHASE_LIMIT")) a->phase_limit = (uint32_t)std::atoi(pl); // profiling aid only
     return ADSB_AMD_OK;
 }
 
@@ -142,7 +145,7 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     s.args.chunk_counts  = s.counts;
     s.args.cap           = (uint32_t)s.cap_per_chunk;
     HIP_TRY(c, hipEventRecord(s.ev_begin, s.stream));
-    HIP_TRY(c, launch_scan1090(s.args, s.dense, s.offsets, s.total_d, s.stream, s.ev_scan0, s.ev_scan1));
+    HIP_TRY(c, launch_scan1090(s.args, s.dense, s.offsets, s.block_sums, s.total_d, s.stream, s.ev_scan0, s.ev_scan1));
     HIP_TRY(c, hipMemcpyAsync(s.total_h, s.total_d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(c, hipEventRecord(s.ev_done, s.stream));
     return ADSB_AMD_OK;
@@ -184,13 +187,9 @@ extern "C" int adsb_amd_create(adsb_amd_ctx_t** out, int device)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
 
-    std::vector<uint16_t> lut(kLutSize);
-    build_mag_lut(lut.data());
     uint32_t tab[112];
     build_crc_table(tab);
-    if ((e = hipMalloc(&c->lut, kLutSize * sizeof(uint16_t))) != hipSuccess) return bail("hipMalloc(lut)", e);
     if ((e = hipMalloc(&c->crc_tab, sizeof(tab))) != hipSuccess) return bail("hipMalloc(crc)", e);
-    if ((e = hipMemcpy(c->lut, lut.data(), kLutSize * sizeof(uint16_t), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(lut)", e);
     if ((e = hipMemcpy(c->crc_tab, tab, sizeof(tab), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(crc)", e);
     for (Slot& s : c->slot)
     {
@@ -222,7 +221,6 @@ extern "C" void adsb_amd_destroy(adsb_amd_ctx_t* c)
         if (s.ev_scan1) (void)hipEventDestroy(s.ev_scan1);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     }
-    if (c->lut) (void)hipFree(c->lut);
     if (c->crc_tab) (void)hipFree(c->crc_tab);
     if (c->lut978) (void)hipFree(c->lut978);
     if (c->staging) (void)hipFree(c->staging);
@@ -359,7 +357,7 @@ extern "C" int adsb_amd_magnitude_1090(adsb_amd_ctx_t* c, const uint8_t* iq_host
     if (rc) return rc;
     uint16_t* d = nullptr;
     HIP_TRY(c, hipMalloc(&d, n * sizeof(uint16_t)));
-    hipError_t e = launch_magnitude1090(c->staging, d, n, c->lut, c->stream);
+    hipError_t e = launch_magnitude1090(c->staging, d, n, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(mag_out, d, n * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);

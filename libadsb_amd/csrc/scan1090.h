@@ -20,7 +20,6 @@ constexpr int kHalo       = 256;                 // >= 240 samples read past the
 constexpr int kFront      = 8;                   // u16 slots before the window; slot 7 = sample g0-1
 constexpr int kTileU16    = kFront + kChunk + kHalo + 8;
 constexpr int kFrameSpan  = 240;                 // (8 + 112) * 2 samples: reference loop bound (ADSB1090.cpp:772)
-constexpr int kLutSize    = 32768;               // magnitude LUT indexed by min(i*i+q*q, 32767)
 
 struct ScanArgs
 {
@@ -30,11 +29,11 @@ struct ScanArgs
     uint32_t           nbuf;
     uint32_t           chunks_per_buf;
     uint32_t           total_chunks;
-    const uint16_t*    lut;          // kLutSize entries
     const uint32_t*    crc_tab;      // 112 entries (ModesChecksumTable semantics)
     adsb_amd_record_t* chunk_records; // total_chunks * cap
     uint32_t*          chunk_counts;  // total_chunks
     uint32_t           cap;           // records per chunk region
+    uint32_t           phase_limit;   // profiling aid: stop after phase N of a chunk (1 load+s, 2 stage1, 3 stage2); 0 = run everything
 };
 
 inline uint32_t chunks_per_buffer(uint32_t buf_samples)
@@ -45,18 +44,18 @@ inline uint32_t chunks_per_buffer(uint32_t buf_samples)
 }
 
 // Enqueue: demodulation kernel, then prefix over the per-chunk counts, then the ordered gather into `dense`.
-// `total_and_overflow` is a device uint32_t[2]: {number of records in dense, overflow flag}.
-hipError_t launch_scan1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t* chunk_offsets, uint32_t* total_and_overflow,
-                           hipStream_t stream, hipEvent_t ev_scan_begin, hipEvent_t ev_scan_end);
+// `total_and_overflow` is a device uint32_t[2]: {number of records in dense, overflow flag}; `block_sums` holds one
+// uint32_t per 1024 chunks.
+hipError_t launch_scan1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t* chunk_offsets, uint32_t* block_sums,
+                           uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t ev_scan_begin, hipEvent_t ev_scan_end);
 
 // magnitudes exactly as the reference computes them (parity helper)
-hipError_t launch_magnitude1090(const uint8_t* iq, uint16_t* mag, size_t nsamples, const uint16_t* lut, hipStream_t stream);
+hipError_t launch_magnitude1090(const uint8_t* iq, uint16_t* mag, size_t nsamples, hipStream_t stream);
 
 // UAT978 phase LUT map (UAT978.cpp:52): phi[k] = lut[I | Q<<8]
 hipError_t launch_phase978(const uint8_t* iq, uint16_t* phi, size_t nsamples, const uint16_t* lut65536, hipStream_t stream);
 
 // host-side table builders (exact integer / polynomial arithmetic, no reference text)
-void build_mag_lut(uint16_t* lut /* kLutSize */);
 void build_crc_table(uint32_t* tab /* 112 */);
 
 } // namespace adsb_amd

@@ -1,0 +1,42 @@
+"""Condense rocprofv3 csv output (kernel trace stats + PMC passes) into a short text summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(sub, pat):
+    return sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True))
+
+
+for f in find("trace", "*kernel_stats.csv"):
+    print("== kernel stats (%s)" % os.path.relpath(f, out))
+    for row in csv.DictReader(open(f)):
+        print("  %-60s calls=%s total_ns=%s avg_ns=%s min=%s max=%s pct=%s" % (
+            row.get("Name", "")[:60], row.get("Calls"), row.get("TotalDurationNs"), row.get("AverageNs"), row.get("MinNs"), row.get("MaxNs"), row.get("Percentage")))
+for f in find("trace", "*kernel_trace.csv"):
+    rows = list(csv.DictReader(open(f)))
+    for r in rows:
+        if "scan1090" in r.get("Kernel_Name", ""):
+            print("== scan1090 dispatch: grid=%s wg=%s vgpr=%s accum=%s sgpr=%s lds=%s scratch=%s" % (
+                r.get("Grid_Size"), r.get("Workgroup_Size"), r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size")))
+            break
+for sub in ("pmc1", "pmc2", "pmc3", "pmc4"):
+    for f in find(sub, "*counter_collection.csv"):
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"][:50]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        print("== %s" % sub)
+        for k, cs in acc.items():
+            if "scan1090" not in k and "gather" not in k and "prefix" not in k:
+                continue
+            print("  " + k)
+            for c, v in sorted(cs.items()):
+                print("     %-24s n=%d mean=%.4g" % (c, len(v), sum(v) / len(v)))
+for f in sorted(glob.glob(os.path.join(out, "bench_*.log"))):
+    lines = [l for l in open(f).read().splitlines() if l.startswith("{")]
+    if lines:
+        print("== %s: %s" % (os.path.basename(f), lines[-1][:400]))
