@@ -61,7 +61,7 @@ typedef struct adsb_amd_record
     uint32_t buffer;   /* index of the reference buffer inside this scan call */
     uint32_t offset;   /* sample index j of the preamble inside that buffer */
     uint32_t addr;     /* DF11/17: bytes 1..3 after repair; AP-type: AP xor parity */
-    uint16_t delta;    /* energy-gate average (ADSB1090.cpp:870-872), saturated to 65535 */
+    uint16_t reserved; /* 0 */
     uint8_t  nbits;    /* 56 / 112, from the DF as sliced (before repair) */
     int8_t   errorbit; /* -1, or the repaired bit (FixSingleBitErrors) */
     uint8_t  df;       /* msg[0]>>3 as sliced (before repair) -- Message::msgtype */

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libadsb_amd.so")
 REF_BUFFER_BYTES = 262144
 F_PASS2, F_PHASE, F_NEEDS_ICAO = 1, 2, 4
 
-RECORD_DTYPE = np.dtype([("buffer", "<u4"), ("offset", "<u4"), ("addr", "<u4"), ("delta", "<u2"), ("nbits", "u1"),
+RECORD_DTYPE = np.dtype([("buffer", "<u4"), ("offset", "<u4"), ("addr", "<u4"), ("reserved", "<u2"), ("nbits", "u1"),
                          ("errorbit", "i1"), ("df", "u1"), ("flags", "u1"), ("msg", "u1", (14,))])
 FRAME_DTYPE = np.dtype([("offset", "<u8"), ("msg", "u1", (14,)), ("nbits", "u1"), ("errorbit", "i1"), ("pass", "u1"),
                         ("phase_applied", "u1"), ("df", "u1"), ("reserved", "u1"), ("addr", "<u4")])

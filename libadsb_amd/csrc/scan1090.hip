@@ -52,12 +52,17 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u
 // Two IQ samples (4 bytes I0 Q0 I1 Q1) -> (s0 | s1 << 16), s = (I-127)^2 + (Q-127)^2 saturated to 32767.
 // 32768 (I = Q = 255) is the only value above 32767 and 32767 itself is not a sum of two squares, so the
 // saturation keeps the order of all reachable values and makes every difference fit in an int16.
+// With I' = 255 - I (a bitwise NOT of the byte): (I-127)^2 = (I'-128)^2 = I' * (I' - 256) + 16384, and I' - 256 as an
+// int16 is just 0xFF00 | I'.  Cheap bit ops, two packed int16 MADs and one saturating packed add per pair of samples.
 __device__ __forceinline__ uint32_t iq2_to_s2(uint32_t x)
 {
-    const u16x2 c  = {127, 127};
-    const i16x2 di = __builtin_bit_cast(i16x2, as_pk(x & 0x00FF00FFu) - c);
-    const i16x2 dq = __builtin_bit_cast(i16x2, as_pk((x >> 8) & 0x00FF00FFu) - c);
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(di * di, dq * dq));
+    const uint32_t y  = x >> 8;
+    const uint32_t ni = ~x & 0x00FF00FFu, hi = ni | 0xFF00FF00u;
+    const uint32_t nq = ~y & 0x00FF00FFu, hq = nq | 0xFF00FF00u;
+    const i16x2    k  = {16384, 16384};
+    const i16x2    a  = __builtin_bit_cast(i16x2, ni) * __builtin_bit_cast(i16x2, hi) + k; // (I-127)^2 in [0, 16384]
+    const i16x2    b  = __builtin_bit_cast(i16x2, nq) * __builtin_bit_cast(i16x2, hq) + k; // (Q-127)^2
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(a, b));
 }
 
 __device__ __forceinline__ uint32_t iq1_to_s(uint32_t i, uint32_t q)
@@ -81,7 +86,20 @@ __device__ __forceinline__ int mag_of_s(uint32_t s)
     return se ? (int)m : 0;
 }
 
+// Float estimate of the same magnitude: |est - 360*sqrt(s)| < 0.05 (v_sqrt_f32 is good to 1 ulp, one more rounding in
+// the multiply; 32767 standing for 32768 costs at most 1.0), hence |est - mag_of_s| < 1.6.
+__device__ __forceinline__ float mag_estimate(uint32_t s) { return __builtin_amdgcn_sqrtf((float)s) * 360.0f; }
+constexpr float kEstErr = 1.6f;
+
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+// Ordering point between LDS writes and reads of other lanes of the same wavefront (single-wave workgroups): the
+// hardware executes one wave's LDS instructions in order, the fence only stops the compiler from reordering them.
+// Unlike __syncthreads() it does not wait for outstanding global loads, so the prefetched window stays in flight.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // ------------------------------------------------------------------------------------------------
 // wave64 scans / reductions on DPP (no LDS round trips): row_shr 1,2,4,8 inside each row of 16, then
@@ -90,7 +108,7 @@ __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
 }
 __device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t x)
 {
@@ -210,7 +228,7 @@ __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap
 
 // Store one record (wave-uniform arguments, lane 0 writes 32 bytes).
 __device__ __forceinline__ void emit_record(Emit& e, int lane, uint32_t offset, uint64_t ra, uint64_t rb, uint32_t df, uint32_t nbits,
-                                            int errorbit, uint32_t flags, uint32_t addr, uint32_t delta)
+                                            int errorbit, uint32_t flags, uint32_t addr)
 {
     if (e.count < e.cap)
     {
@@ -218,12 +236,11 @@ __device__ __forceinline__ void emit_record(Emit& e, int lane, uint32_t offset, 
         {
             uint32_t m0 = bswap32((uint32_t)(ra >> 32)), m1 = bswap32((uint32_t)ra);
             uint32_t m2 = bswap32((uint32_t)(rb >> 32)), m3 = bswap32((uint32_t)rb);
-            uint32_t d16 = delta > 65535u ? 65535u : delta;
             uint4    lo, hi;
             lo.x = e.buffer;
             lo.y = offset;
             lo.z = addr;
-            lo.w = d16 | (nbits << 16) | (((uint32_t)errorbit & 0xFFu) << 24);
+            lo.w = (nbits << 16) | (((uint32_t)errorbit & 0xFFu) << 24);
             hi.x = df | (flags << 8) | (m0 << 16);
             hi.y = (m0 >> 16) | (m1 << 16);
             hi.z = (m1 >> 16) | (m2 << 16);
@@ -243,7 +260,7 @@ __device__ __forceinline__ bool df_is_ap(uint32_t df) { return df == 0 || df == 
 // LSB = lowest bit index).  *stateless is set when the frame is one the reference accepts without consulting
 // the ICAO cache (DF11/17 with good or repaired parity).
 __device__ __forceinline__ void classify_and_emit(Emit& e, int lane, const LaneTables& lt, uint64_t ba, uint64_t bb, uint32_t df,
-                                                  uint32_t nbits, uint32_t offset, uint32_t flags, uint32_t delta, bool* stateless)
+                                                  uint32_t nbits, uint32_t offset, uint32_t flags, bool* stateless)
 {
     *stateless      = false;
     const bool is17 = (df == 11 || df == 17);
@@ -291,43 +308,79 @@ __device__ __forceinline__ void classify_and_emit(Emit& e, int lane, const LaneT
         }
         *stateless    = true;
         uint32_t addr = (uint32_t)(ra >> 32) & 0xFFFFFFu;
-        emit_record(e, lane, offset, ra, rb, df, nbits, errorbit, flags, addr, delta);
+        emit_record(e, lane, offset, ra, rb, df, nbits, errorbit, flags, addr);
         return;
     }
     // AP-type: address candidate = AP xor parity (:418-425); validity is decided against the ICAO cache on the host
-    emit_record(e, lane, offset, ra, rb, df, nbits, -1, flags | ADSB_AMD_F_NEEDS_ICAO, syn, delta);
+    emit_record(e, lane, offset, ra, rb, df, nbits, -1, flags | ADSB_AMD_F_NEEDS_ICAO, syn);
 }
 
+// Exact per-lane slicing inputs of one candidate (reference magnitudes of the two samples of bit `lane` and bit 64+lane).
+struct BitMags
+{
+    int loA, hiA, loB, hiB;
+};
+
 // Demodulate the candidate whose preamble starts at tile index w0 (sample j of the buffer).
+//
+// Pass 1 is first attempted on float magnitude estimates: which half of a bit is larger is an exact comparison of s
+// (the magnitude is strictly increasing in s), "|lo-hi| >= 256" (:838) and the energy gate (:870-877) are decided from
+// the estimates whenever they are further from their thresholds than the estimate's error bound.  Only when some
+// decision is inside that margin -- or the retry slice, which rescales exact magnitudes, is needed -- are the exact
+// magnitudes computed.  Either way the bits that come out are exactly the reference's.
 __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, const LaneTables& lt, Emit& e, int w0, uint32_t j)
 {
     const bool has_b = lane < 48;
     // bit `lane` lives in samples j+16+2*lane, j+17+2*lane; bit 64+lane another 128 samples on (ADSB1090.cpp:831-835)
-    const int ia  = w0 + 16 + 2 * lane;
-    const int ib  = has_b ? ia + 128 : ia;
-    const int loA = mag_of_s(tile[ia]), hiA = mag_of_s(tile[ia + 1]);
-    const int loB = mag_of_s(tile[ib]), hiB = mag_of_s(tile[ib + 1]);
+    const int      ia  = w0 + 16 + 2 * lane;
+    const int      ib  = has_b ? ia + 128 : ia;
+    const uint32_t sLoA = tile[ia], sHiA = tile[ia + 1], sLoB = tile[ib], sHiB = tile[ib + 1];
 
     // bit 0 with equal halves is the reference's only reachable "errors++" (:839-846); it survives the retry
-    // unchanged (sample j+16 is never rescaled), so such a candidate can never be decoded.
-    if (__builtin_amdgcn_readfirstlane((int)(loA == hiA))) return;
+    // unchanged (sample j+16 is never rescaled), so such a candidate can never be decoded.  m equal <=> s equal.
+    if (__builtin_amdgcn_readfirstlane((int)(sLoA == sHiA))) return;
 
-    const int dA = abs(loA - hiA);
-    const int dB = has_b ? abs(loB - hiB) : 0;
-
-    // energy sums over the untouched samples (:870-872): first 56 bits, and the rest
-    const uint32_t sum56   = wave_sum(lane < 56 ? (uint32_t)dA : 0u);
-    const uint32_t sumrest = wave_sum((lane >= 56 ? (uint32_t)dA : 0u) + (uint32_t)dB);
-
-    // ---------------- pass 1: plain slice (:831-853)
-    uint64_t ba, bb;
-    slice_resolve(lane, has_b, lane == 0 || dA >= 256, loA > hiA, dB >= 256, loB > hiB, &ba, &bb);
-    uint32_t df    = (uint32_t)(__builtin_bitreverse64(ba) >> 59);
-    uint32_t nbits = df_is_long(df) ? 112u : 56u;
-    uint32_t delta = (nbits == 112u) ? (sum56 + sumrest) / 56u : sum56 / 28u;
-    if (delta < 2550u) return; // :877-881, no retry either
+    const bool valA = sLoA > sHiA, valB = has_b && (sLoB > sHiB);
+    BitMags    x{};
+    bool       have_exact = false;
+    uint32_t   sum56 = 0, sumrest = 0;
+    uint64_t   ba = 0, bb = 0;
+    uint32_t   df = 0, nbits = 0;
+    {
+        // ---------------- pass 1 on estimates
+        const float fA = __builtin_fabsf(mag_estimate(sLoA) - mag_estimate(sHiA));
+        const float fB = has_b ? __builtin_fabsf(mag_estimate(sLoB) - mag_estimate(sHiB)) : 0.0f;
+        const float lo_edge = 256.0f - 2.0f * kEstErr, hi_edge = 256.0f + 2.0f * kEstErr;
+        const bool  unsure  = (lane != 0 && fA > lo_edge && fA < hi_edge) || (has_b && fB > lo_edge && fB < hi_edge);
+        bool        need_exact = ballot(unsure) != 0;
+        if (!need_exact)
+        {
+            const uint32_t iA = (uint32_t)(fA + 0.5f), iB = (uint32_t)(fB + 0.5f);
+            const uint32_t e56 = wave_sum(lane < 56 ? iA : 0u), erest = wave_sum((lane >= 56 ? iA : 0u) + iB);
+            slice_resolve(lane, has_b, lane == 0 || fA >= hi_edge, valA, fB >= hi_edge, valB, &ba, &bb);
+            df    = (uint32_t)(__builtin_bitreverse64(ba) >> 59);
+            nbits = df_is_long(df) ? 112u : 56u;
+            // each |lo-hi| estimate is within 2*kEstErr + 0.5 of the true integer, so is the average
+            const uint32_t avg = (nbits == 112u) ? (e56 + erest) / 56u : e56 / 28u;
+            if (avg + 5u < 2550u) return;        // surely below the gate (:877-881): dead, no retry
+            if (avg < 2550u + 5u) need_exact = true; // too close to call
+        }
+        if (need_exact)
+        {
+            x.loA = mag_of_s(sLoA); x.hiA = mag_of_s(sHiA); x.loB = mag_of_s(sLoB); x.hiB = mag_of_s(sHiB);
+            have_exact   = true;
+            const int dA = abs(x.loA - x.hiA), dB = has_b ? abs(x.loB - x.hiB) : 0;
+            sum56        = wave_sum(lane < 56 ? (uint32_t)dA : 0u);
+            sumrest      = wave_sum((lane >= 56 ? (uint32_t)dA : 0u) + (uint32_t)dB);
+            slice_resolve(lane, has_b, lane == 0 || dA >= 256, valA, dB >= 256, valB, &ba, &bb);
+            df    = (uint32_t)(__builtin_bitreverse64(ba) >> 59);
+            nbits = df_is_long(df) ? 112u : 56u;
+            const uint32_t delta = (nbits == 112u) ? (sum56 + sumrest) / 56u : sum56 / 28u;
+            if (delta < 2550u) return; // :877-881, no retry either
+        }
+    }
     bool stateless = false;
-    classify_and_emit(e, lane, lt, ba, bb, df, nbits, j, 0u, delta, &stateless);
+    classify_and_emit(e, lane, lt, ba, bb, df, nbits, j, 0u, &stateless);
     if (stateless) return; // the reference accepts here and never retries
 
     // ---------------- pass 2: retry with phase correction (:814-826); identical to pass 1 unless the window is rescaled
@@ -340,6 +393,14 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
     // x > y/3 (integer division)  <=>  3x > y
     const bool oop = (3 * m3 > m2) || (3 * m10 > m9) || (3 * m6 > m7) || (3 * m_1 > m1);
     if (!oop) return;
+    if (!have_exact)
+    {
+        x.loA = mag_of_s(sLoA); x.hiA = mag_of_s(sHiA); x.loB = mag_of_s(sLoB); x.hiB = mag_of_s(sHiB);
+        const int dA = abs(x.loA - x.hiA), dB = has_b ? abs(x.loB - x.hiB) : 0;
+        sum56        = wave_sum(lane < 56 ? (uint32_t)dA : 0u);
+        sumrest      = wave_sum((lane >= 56 ? (uint32_t)dA : 0u) + (uint32_t)dB);
+    }
+    const int loA = x.loA, hiA = x.hiA, loB = x.loB, hiB = x.hiB;
 
     // ApplyPhaseCorrection (:720-736): the first sample of bit k>=1 becomes up(x) or dn(x) (u16 wrap) depending on
     // whether the (already rescaled) first sample of bit k-1 exceeds its second sample.
@@ -377,9 +438,9 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
     slice_resolve(lane, has_b, lane == 0 || d2A >= 256, lo2A > hiA, d2B >= 256, lo2B > hiB, &ba, &bb);
     df    = (uint32_t)(__builtin_bitreverse64(ba) >> 59);
     nbits = df_is_long(df) ? 112u : 56u;
-    delta = (nbits == 112u) ? (sum56 + sumrest) / 56u : sum56 / 28u; // window is restored before the gate (:855-856)
-    if (delta < 2550u) return;
-    classify_and_emit(e, lane, lt, ba, bb, df, nbits, j, ADSB_AMD_F_PASS2 | ADSB_AMD_F_PHASE, delta, &stateless);
+    const uint32_t delta2 = (nbits == 112u) ? (sum56 + sumrest) / 56u : sum56 / 28u; // window is restored before the gate (:855-856)
+    if (delta2 < 2550u) return;
+    classify_and_emit(e, lane, lt, ba, bb, df, nbits, j, ADSB_AMD_F_PASS2 | ADSB_AMD_F_PHASE, &stateless);
 }
 
 struct ChunkGeom
@@ -479,7 +540,7 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
     for (;;)
     {
         // ---------------- s = (I-127)^2 + (Q-127)^2 for the window, parked in LDS
-        __syncthreads(); // readers of the previous chunk are done (single-wave workgroup)
+        wave_lds_fence(); // readers of the previous chunk are done
 #pragma unroll
         for (int r = 0; r <= kRows; r++)
         {
@@ -501,7 +562,7 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
             g = chunk_geom(a, next);
             load_window(g, lane, raw);
         }
-        __syncthreads();
+        wave_lds_fence();
         if (a.phase_limit == 1)
         {
             if (next >= end) break;
@@ -578,7 +639,7 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
                     idx++;
                 }
             }
-            __syncthreads();
+            wave_lds_fence();
             const uint32_t nq = (n1 - base < (uint32_t)kQueueCap) ? (n1 - base) : (uint32_t)kQueueCap;
 
             // stage 2 (:794-811), dense over lanes; survivors are compacted in place
@@ -590,17 +651,25 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
                 uint32_t       pos = 0;
                 if (idx < nq)
                 {
-                    pos            = queue[idx];
-                    const int w    = kFront + (int)pos;
-                    const int high = (mag_of_s(tile[w]) + mag_of_s(tile[w + 2]) + mag_of_s(tile[w + 7]) + mag_of_s(tile[w + 9])) / 6;
-                    ok = mag_of_s(tile[w + 4]) < high && mag_of_s(tile[w + 5]) < high && mag_of_s(tile[w + 11]) < high
-                         && mag_of_s(tile[w + 12]) < high && mag_of_s(tile[w + 13]) < high && mag_of_s(tile[w + 14]) < high;
+                    // high = (m0+m2+m7+m9)/6 needs four exact magnitudes; "m_x < high" for the six quiet samples is then
+                    // one test on the largest of their s values: m(s) <= high-1  <=>  129600*s <= high^2 - high.
+                    pos                 = queue[idx];
+                    const int      w    = kFront + (int)pos;
+                    const uint32_t high = (uint32_t)(mag_of_s(tile[w]) + mag_of_s(tile[w + 2]) + mag_of_s(tile[w + 7]) + mag_of_s(tile[w + 9])) / 6u;
+                    uint32_t       sq   = tile[w + 4];
+                    sq = (tile[w + 5] > sq) ? tile[w + 5] : sq;
+                    sq = (tile[w + 11] > sq) ? tile[w + 11] : sq;
+                    sq = (tile[w + 12] > sq) ? tile[w + 12] : sq;
+                    sq = (tile[w + 13] > sq) ? tile[w + 13] : sq;
+                    sq = (tile[w + 14] > sq) ? tile[w + 14] : sq;
+                    const uint32_t se = sq + ((sq + 1u) >> 15);
+                    ok = high != 0 && (uint32_t)__umul24(se, 129600u) <= high * high - high;
                 }
                 const uint64_t mk = ballot(ok);
                 if (ok) queue[n2 + (uint32_t)__builtin_popcountll(mk & ((1ull << lane) - 1ull))] = (uint16_t)pos;
                 n2 += (uint32_t)__builtin_popcountll(mk);
             }
-            __syncthreads();
+            wave_lds_fence();
 
             // demodulate the candidates, one at a time, whole wave each
             if (a.phase_limit == 3) n2 = 0;
@@ -609,7 +678,7 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
                 const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)queue[t]);
                 demod_candidate(tile, lane, lt, e, kFront + (int)pos, cur.g0 + pos);
             }
-            __syncthreads();
+            wave_lds_fence();
         }
         if (lane == 0) a.chunk_counts[me] = e.count;
 

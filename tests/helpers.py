@@ -15,7 +15,6 @@ AP_DFS = (0, 4, 5, 16, 20, 21, 24)
 def _rec(buffer, j, msg, nbits, errorbit, df, flags, addr, delta):
     r = np.zeros(1, dtype=A.RECORD_DTYPE)[0]
     r["buffer"], r["offset"], r["addr"] = buffer, j, addr
-    r["delta"] = min(int(delta), 65535)
     r["nbits"], r["errorbit"], r["df"], r["flags"] = nbits, errorbit, df, flags
     r["msg"] = np.frombuffer(bytes(msg), dtype=np.uint8)
     return r

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(native_libs):
 
 def test_record_layout_matches_header():
     assert A.RECORD_DTYPE.itemsize == 32
-    assert [A.RECORD_DTYPE.fields[n][1] for n in ("buffer", "offset", "addr", "delta", "nbits", "errorbit", "df", "flags", "msg")] == \
+    assert [A.RECORD_DTYPE.fields[n][1] for n in ("buffer", "offset", "addr", "reserved", "nbits", "errorbit", "df", "flags", "msg")] == \
         [0, 4, 8, 12, 14, 15, 16, 17, 18]
 
 
