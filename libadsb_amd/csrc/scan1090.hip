@@ -218,36 +218,32 @@ __device__ __forceinline__ LaneTables load_lane_tables(const uint32_t* __restric
 
 struct Emit
 {
-    adsb_amd_record_t* base; // this chunk's region
-    uint32_t           cap;
-    uint32_t           count; // wave-uniform
-    uint32_t           buffer;
+    uint4*   base; // this chunk's region, one raw record = 2 x uint4
+    uint32_t cap;
+    uint32_t count; // wave-uniform
 };
 
-__device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
-
-// Store one record (wave-uniform arguments, lane 0 writes 32 bytes).
-__device__ __forceinline__ void emit_record(Emit& e, int lane, uint32_t offset, uint64_t ra, uint64_t rb, uint32_t df, uint32_t nbits,
-                                            int errorbit, uint32_t flags, uint32_t addr)
+// A raw record is what the wave has in scalar registers anyway; turning it into the public adsb_amd_record_t (byte
+// order, repair flip, address extraction) is done later by the gather kernel, one record per lane.
+//   lo = { offset, df | nbits<<8 | flags<<16 | (errorbit+1)<<24, AP xor parity, 0 },  hi = message bits 0..127 (bit n = bit n)
+__device__ __forceinline__ void emit_raw(Emit& e, int lane, uint32_t offset, uint64_t ba, uint64_t bb, uint32_t df, uint32_t nbits,
+                                         int errorbit, uint32_t flags, uint32_t syn)
 {
     if (e.count < e.cap)
     {
         if (lane == 0)
         {
-            uint32_t m0 = bswap32((uint32_t)(ra >> 32)), m1 = bswap32((uint32_t)ra);
-            uint32_t m2 = bswap32((uint32_t)(rb >> 32)), m3 = bswap32((uint32_t)rb);
-            uint4    lo, hi;
-            lo.x = e.buffer;
-            lo.y = offset;
-            lo.z = addr;
-            lo.w = (nbits << 16) | (((uint32_t)errorbit & 0xFFu) << 24);
-            hi.x = df | (flags << 8) | (m0 << 16);
-            hi.y = (m0 >> 16) | (m1 << 16);
-            hi.z = (m1 >> 16) | (m2 << 16);
-            hi.w = (m2 >> 16) | (m3 << 16);
-            uint4* dst = reinterpret_cast<uint4*>(e.base + e.count);
-            dst[0]     = lo;
-            dst[1]     = hi;
+            uint4 lo, hi;
+            lo.x = offset;
+            lo.y = df | (nbits << 8) | (flags << 16) | ((uint32_t)(errorbit + 1) << 24);
+            lo.z = syn;
+            lo.w = 0;
+            hi.x = (uint32_t)ba;
+            hi.y = (uint32_t)(ba >> 32);
+            hi.z = (uint32_t)bb;
+            hi.w = (uint32_t)(bb >> 32);
+            e.base[2 * e.count]     = lo;
+            e.base[2 * e.count + 1] = hi;
         }
     }
     e.count++; // counts past cap signal overflow to the ordering pass
@@ -269,19 +265,17 @@ __device__ __forceinline__ void classify_and_emit(Emit& e, int lane, const LaneT
     const bool bit_a = (ba >> lane) & 1ull;
     const bool bit_b = (lane < 48) && ((bb >> lane) & 1ull);
     uint32_t   contrib, stored;
-    uint64_t   ra = __builtin_bitreverse64(ba), rb = __builtin_bitreverse64(bb);
     if (nbits == 112)
     {
         contrib = (bit_a ? lt.crc_a : 0u) ^ (bit_b ? lt.crc_b : 0u);
-        stored  = (uint32_t)(rb >> 16) & 0xFFFFFFu;
+        stored  = (uint32_t)(__builtin_bitreverse64(bb) >> 16) & 0xFFFFFFu; // message bits 88..111, first bit = MSB
     }
     else
     {
         contrib = (bit_a && lane < 56) ? lt.crc_s : 0u;
-        stored  = (uint32_t)(ra >> 8) & 0xFFFFFFu;
+        stored  = (uint32_t)(__builtin_bitreverse64(ba) >> 8) & 0xFFFFFFu; // message bits 32..55
     }
-    const uint32_t crc = wave_xor(contrib);
-    const uint32_t syn = crc ^ stored;
+    const uint32_t syn = wave_xor(contrib) ^ stored;
     if (is17)
     {
         int errorbit = -1;
@@ -301,18 +295,13 @@ __device__ __forceinline__ void classify_and_emit(Emit& e, int lane, const LaneT
                 if (ms) errorbit = __builtin_ctzll(ms);
             }
             if (errorbit < 0) return;
-            if (errorbit < 64) ba ^= (1ull << errorbit);
-            else bb ^= (1ull << (errorbit - 64));
-            ra = __builtin_bitreverse64(ba);
-            rb = __builtin_bitreverse64(bb);
         }
-        *stateless    = true;
-        uint32_t addr = (uint32_t)(ra >> 32) & 0xFFFFFFu;
-        emit_record(e, lane, offset, ra, rb, df, nbits, errorbit, flags, addr);
+        *stateless = true;
+        emit_raw(e, lane, offset, ba, bb, df, nbits, errorbit, flags, 0u);
         return;
     }
     // AP-type: address candidate = AP xor parity (:418-425); validity is decided against the ICAO cache on the host
-    emit_record(e, lane, offset, ra, rb, df, nbits, -1, flags | ADSB_AMD_F_NEEDS_ICAO, syn);
+    emit_raw(e, lane, offset, ba, bb, df, nbits, -1, flags | ADSB_AMD_F_NEEDS_ICAO, syn);
 }
 
 // Exact per-lane slicing inputs of one candidate (reference magnitudes of the two samples of bit `lane` and bit 64+lane).
@@ -351,19 +340,32 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
         const float fA = __builtin_fabsf(mag_estimate(sLoA) - mag_estimate(sHiA));
         const float fB = has_b ? __builtin_fabsf(mag_estimate(sLoB) - mag_estimate(sHiB)) : 0.0f;
         const float lo_edge = 256.0f - 2.0f * kEstErr, hi_edge = 256.0f + 2.0f * kEstErr;
-        const bool  unsure  = (lane != 0 && fA > lo_edge && fA < hi_edge) || (has_b && fB > lo_edge && fB < hi_edge);
-        bool        need_exact = ballot(unsure) != 0;
-        if (!need_exact)
+        bool        need_exact = false;
+        // Strong clean frame: every one of the 112 bits has |lo-hi| far above both the "decided" threshold and the
+        // energy-gate average, so the value ballots are the message and the gate passes for either length.
+        if (ballot(fA >= 2560.0f) == ~0ull && ballot(has_b && fB >= 2560.0f) == kMask48)
         {
-            const uint32_t iA = (uint32_t)(fA + 0.5f), iB = (uint32_t)(fB + 0.5f);
-            const uint32_t e56 = wave_sum(lane < 56 ? iA : 0u), erest = wave_sum((lane >= 56 ? iA : 0u) + iB);
-            slice_resolve(lane, has_b, lane == 0 || fA >= hi_edge, valA, fB >= hi_edge, valB, &ba, &bb);
+            ba    = ballot(valA);
+            bb    = ballot(valB);
             df    = (uint32_t)(__builtin_bitreverse64(ba) >> 59);
             nbits = df_is_long(df) ? 112u : 56u;
-            // each |lo-hi| estimate is within 2*kEstErr + 0.5 of the true integer, so is the average
-            const uint32_t avg = (nbits == 112u) ? (e56 + erest) / 56u : e56 / 28u;
-            if (avg + 5u < 2550u) return;        // surely below the gate (:877-881): dead, no retry
-            if (avg < 2550u + 5u) need_exact = true; // too close to call
+        }
+        else
+        {
+            const bool unsure = (lane != 0 && fA > lo_edge && fA < hi_edge) || (has_b && fB > lo_edge && fB < hi_edge);
+            need_exact        = ballot(unsure) != 0;
+            if (!need_exact)
+            {
+                const uint32_t iA = (uint32_t)(fA + 0.5f), iB = (uint32_t)(fB + 0.5f);
+                const uint32_t e56 = wave_sum(lane < 56 ? iA : 0u), erest = wave_sum((lane >= 56 ? iA : 0u) + iB);
+                slice_resolve(lane, has_b, lane == 0 || fA >= hi_edge, valA, fB >= hi_edge, valB, &ba, &bb);
+                df    = (uint32_t)(__builtin_bitreverse64(ba) >> 59);
+                nbits = df_is_long(df) ? 112u : 56u;
+                // each |lo-hi| estimate is within 2*kEstErr + 0.5 of the true integer, so is the average
+                const uint32_t avg = (nbits == 112u) ? (e56 + erest) / 56u : e56 / 28u;
+                if (avg + 5u < 2550u) return;        // surely below the gate (:877-881): dead, no retry
+                if (avg < 2550u + 5u) need_exact = true; // too close to call
+            }
         }
         if (need_exact)
         {
@@ -452,11 +454,10 @@ struct ChunkGeom
     uint32_t       n;    // samples in the buffer
 };
 
-__device__ __forceinline__ ChunkGeom chunk_geom(const ScanArgs& a, uint32_t chunk)
+__device__ __forceinline__ ChunkGeom chunk_geom(const ScanArgs& a, uint32_t bidx, uint32_t cidx)
 {
     ChunkGeom g;
-    g.bidx               = chunk / a.chunks_per_buf;
-    const uint32_t cidx  = chunk - g.bidx * a.chunks_per_buf;
+    g.bidx               = bidx;
     g.n                  = a.buf_samples;
     g.g0                 = cidx * (uint32_t)kChunk;
     const uint32_t limit = g.n - (uint32_t)kFrameSpan; // positions j < limit
@@ -533,7 +534,20 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
 
     uint32_t chunk = first + slot;
     if (chunk >= end) return;
-    ChunkGeom g = chunk_geom(a, chunk);
+
+    // The waves that share a SIMD run the same periodic program (memory phase, VALU-bound gates, latency-bound
+    // demodulation); started together they stay in lockstep and the phases never overlap.  Offsetting each wave by its
+    // hardware slot (HW_ID.wave_id, bits 3:0) spreads them over the period so one wave's loads and dependency chains
+    // hide under another's arithmetic.  Purely a scheduling hint: results do not depend on it.
+    if (a.stagger)
+    {
+        const uint32_t wslot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;
+        for (uint32_t k = 0; k < wslot * a.stagger; k++) __builtin_amdgcn_s_sleep(127);
+    }
+    // (buffer, chunk-in-buffer) of the current chunk, advanced by the constant stride without dividing in the loop
+    const uint32_t step_b = nslot / a.chunks_per_buf, step_c = nslot - step_b * a.chunks_per_buf;
+    uint32_t       bidx = chunk / a.chunks_per_buf, cidx = chunk - bidx * a.chunks_per_buf;
+    ChunkGeom      g    = chunk_geom(a, bidx, cidx);
     RawWindow raw;
     load_window(g, lane, raw);
 
@@ -559,7 +573,14 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
         const uint32_t  next = chunk + nslot;
         if (next < end)
         {
-            g = chunk_geom(a, next);
+            bidx += step_b;
+            cidx += step_c;
+            if (cidx >= a.chunks_per_buf)
+            {
+                cidx -= a.chunks_per_buf;
+                bidx++;
+            }
+            g = chunk_geom(a, bidx, cidx);
             load_window(g, lane, raw);
         }
         wave_lds_fence();
@@ -570,27 +591,30 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
             continue;
         }
 
-        // ---------------- stage 1 on packed s: positions (2i, 2i+1) of this lane's 8, i = 0..3
+        // ---------------- stage 1 on packed s.  A lane takes 16 consecutive positions (pairs (2i, 2i+1), i = 0..7) of a
+        // 1024-position super-row, so the 9-sample look-ahead is amortised over twice as many positions.
         uint64_t surv = 0;
 #pragma unroll 1
-        for (int r = 0; r < kRows; r++)
+        for (int sr = 0; sr < kChunk / 1024; sr++)
         {
-            uint32_t    p0[9];
-            const int   w  = kFront + r * kRowSamples + 8 * lane;
-            const uint4 ow = *reinterpret_cast<const uint4*>(&tile[w]);
-            const uint4 nx = *reinterpret_cast<const uint4*>(&tile[w + 8]);
-            p0[0] = ow.x; p0[1] = ow.y; p0[2] = ow.z; p0[3] = ow.w;
-            p0[4] = nx.x; p0[5] = nx.y; p0[6] = nx.z; p0[7] = nx.w;
-            p0[8] = *reinterpret_cast<const uint32_t*>(&tile[w + 16]);
-            uint32_t p1[8]; // odd-aligned pairs (s[2i+1], s[2i+2])
+            uint32_t    p0[13];
+            const int   w  = kFront + sr * 1024 + 16 * lane;
+            const uint4 q0 = *reinterpret_cast<const uint4*>(&tile[w]);
+            const uint4 q1 = *reinterpret_cast<const uint4*>(&tile[w + 8]);
+            const uint4 q2 = *reinterpret_cast<const uint4*>(&tile[w + 16]);
+            p0[0] = q0.x; p0[1] = q0.y; p0[2] = q0.z; p0[3] = q0.w;
+            p0[4] = q1.x; p0[5] = q1.y; p0[6] = q1.z; p0[7] = q1.w;
+            p0[8] = q2.x; p0[9] = q2.y; p0[10] = q2.z; p0[11] = q2.w;
+            p0[12] = *reinterpret_cast<const uint32_t*>(&tile[w + 24]);
+            uint32_t p1[12]; // odd-aligned pairs (s[2i+1], s[2i+2])
 #pragma unroll
-            for (int i = 0; i < 8; i++) p1[i] = __builtin_amdgcn_alignbit(p0[i + 1], p0[i], 16);
-            uint32_t m2o[6]; // (max(s[2i+1],s[2i+2]), max(s[2i+2],s[2i+3]))
+            for (int i = 0; i < 12; i++) p1[i] = __builtin_amdgcn_alignbit(p0[i + 1], p0[i], 16);
+            uint32_t m2o[10]; // (max(s[2i+1],s[2i+2]), max(s[2i+2],s[2i+3]))
 #pragma unroll
-            for (int i = 1; i <= 5; i++) m2o[i] = pk_max(p1[i], p0[i + 1]);
+            for (int i = 1; i <= 9; i++) m2o[i] = pk_max(p1[i], p0[i + 1]);
             uint32_t bits = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 8; i++)
             {
                 // with j = 2i (low half) / 2i+1 (high half), m_k = s[j+k]:
                 const uint32_t mx36 = pk_max(m2o[i + 1], m2o[i + 2]);                  // max(m3..m6)
@@ -600,13 +624,13 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
                 const uint32_t d3   = pk_sub(p0[i + 4], pk_min(p1[i + 3], p1[i + 4])); // m8 < min(m7,m9)
                 const uint32_t d4   = pk_sub(p0[i + 3], p1[i + 4]);                    // m6 < m9
                 const uint32_t ok   = (d1 & d2 & d3 & d4) & 0x80008000u;
-                bits |= ((ok >> 15) | (ok >> 30)) << (2 * i); // bit 15 -> 0, bit 31 -> 1 (stray bit 16 masked below)
+                bits |= ((ok >> 15) | (ok >> 30)) << (2 * i); // bit 15 -> 0, bit 31 -> 1 (stray high bits masked below)
             }
-            bits &= 0xFFu;
-            const int first_pos = r * kRowSamples + 8 * lane;
+            bits &= 0xFFFFu;
+            const int first_pos = sr * 1024 + 16 * lane;
             const int nvalid    = (int)cur.npos - first_pos;
-            if (nvalid < 8) bits &= (nvalid <= 0) ? 0u : ((1u << nvalid) - 1u);
-            surv |= (uint64_t)bits << (8 * r);
+            if (nvalid < 16) bits &= (nvalid <= 0) ? 0u : ((1u << nvalid) - 1u);
+            surv |= (uint64_t)bits << (16 * sr);
         }
 
         if (a.phase_limit == 2)
@@ -622,10 +646,9 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
         const uint32_t incl = wave_incl_scan_add(mine);
         const uint32_t n1   = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         Emit           e;
-        e.base   = a.chunk_records + (uint64_t)me * a.cap;
-        e.cap    = a.cap;
-        e.count  = 0;
-        e.buffer = cur.bidx;
+        e.base  = reinterpret_cast<uint4*>(a.chunk_records + (uint64_t)me * a.cap);
+        e.cap   = a.cap;
+        e.count = 0;
         for (uint32_t base = 0; base < n1; base += (uint32_t)kQueueCap)
         {
             {
@@ -635,7 +658,7 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
                 {
                     const int b = __builtin_ctzll(sv);
                     sv &= sv - 1;
-                    if (idx - base < (uint32_t)kQueueCap) queue[idx - base] = (uint16_t)((b >> 3) * kRowSamples + 8 * lane + (b & 7));
+                    if (idx - base < (uint32_t)kQueueCap) queue[idx - base] = (uint16_t)((b >> 4) * 1024 + 16 * lane + (b & 15));
                     idx++;
                 }
             }
@@ -746,10 +769,13 @@ __global__ __launch_bounds__(1024) void scan_top_kernel(uint32_t* __restrict__ b
     if (threadIdx.x == 0) total_overflow[0] = carry;
 }
 
+// reverse the bit order inside each byte: message bit n (n = 8k + b, b = 0 first/MSB) -> bit 7-b of byte k
+__device__ __forceinline__ uint32_t msg_bytes(uint32_t bits) { return __builtin_bswap32(__builtin_bitreverse32(bits)); }
+
 __global__ __launch_bounds__(256) void gather_sorted_kernel(const adsb_amd_record_t* __restrict__ chunk_records,
                                                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
                                                             const uint32_t* __restrict__ block_base, uint32_t nchunks, uint32_t cap,
-                                                            adsb_amd_record_t* __restrict__ dense)
+                                                            uint32_t chunks_per_buf, adsb_amd_record_t* __restrict__ dense)
 {
     const int      lane   = threadIdx.x & 63;
     const uint32_t wave   = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -759,23 +785,45 @@ __global__ __launch_bounds__(256) void gather_sorted_kernel(const adsb_amd_recor
         uint32_t n = counts[c];
         if (n == 0) continue;
         if (n > cap) n = cap;
-        const adsb_amd_record_t* src = chunk_records + (uint64_t)c * cap;
-        adsb_amd_record_t*       dst = dense + (block_base[c >> 10] + offsets[c]);
+        const uint4*       src = reinterpret_cast<const uint4*>(chunk_records + (uint64_t)c * cap);
+        adsb_amd_record_t* dst = dense + (block_base[c >> 10] + offsets[c]);
+        const uint32_t     buffer = c / chunks_per_buf;
         for (uint32_t i = (uint32_t)lane; i < n; i += 64)
         {
-            const uint4*   p    = reinterpret_cast<const uint4*>(src + i);
-            const uint4    lo   = p[0], hi = p[1];
-            const uint32_t key  = (lo.y << 1) | ((hi.x >> 8) & 1u); // (offset, pass)
+            const uint4    lo   = src[2 * i];
+            uint4          hi   = src[2 * i + 1];
+            const uint32_t key  = (lo.x << 1) | ((lo.y >> 16) & 1u); // (offset, pass)
             uint32_t       rank = 0;
             for (uint32_t k = 0; k < n; k++)
             {
-                const uint32_t* q  = reinterpret_cast<const uint32_t*>(src + k);
-                const uint32_t  kk = (q[1] << 1) | ((q[4] >> 8) & 1u);
-                rank += (kk < key) ? 1u : 0u;
+                const uint4 q = src[2 * k];
+                rank += (((q.x << 1) | ((q.y >> 16) & 1u)) < key) ? 1u : 0u;
             }
+            // raw -> adsb_amd_record_t: apply the 1-bit repair, order the bytes, pull the address out
+            const uint32_t df = lo.y & 0xFFu, nbits = (lo.y >> 8) & 0xFFu, flags = (lo.y >> 16) & 0xFFu;
+            const int      errorbit = (int)(lo.y >> 24) - 1;
+            if (errorbit >= 0)
+            {
+                const uint32_t m = 1u << (errorbit & 31);
+                if (errorbit < 32) hi.x ^= m;
+                else if (errorbit < 64) hi.y ^= m;
+                else if (errorbit < 96) hi.z ^= m;
+                else hi.w ^= m;
+            }
+            const uint32_t m0 = msg_bytes(hi.x), m1 = msg_bytes(hi.y), m2 = msg_bytes(hi.z), m3 = msg_bytes(hi.w); // bytes 0-3, 4-7, 8-11, 12-13
+            const uint32_t addr = (flags & ADSB_AMD_F_NEEDS_ICAO) ? lo.z : (((m0 >> 8) & 0xFFu) << 16 | ((m0 >> 16) & 0xFFu) << 8 | (m0 >> 24));
+            uint4 o0, o1;
+            o0.x = buffer;
+            o0.y = lo.x;
+            o0.z = addr;
+            o0.w = (nbits << 16) | (((uint32_t)errorbit & 0xFFu) << 24);
+            o1.x = df | (flags << 8) | (m0 << 16);
+            o1.y = (m0 >> 16) | (m1 << 16);
+            o1.z = (m1 >> 16) | (m2 << 16);
+            o1.w = (m2 >> 16) | (m3 << 16);
             uint4* o = reinterpret_cast<uint4*>(dst + rank);
-            o[0]     = lo;
-            o[1]     = hi;
+            o[0]     = o0;
+            o[1]     = o1;
         }
     }
 }
@@ -827,7 +875,7 @@ hipError_t launch_scan1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t
     uint32_t gblocks = (a.total_chunks + 3u) / 4u;
     if (gblocks > 4096u) gblocks = 4096u;
     hipLaunchKernelGGL(gather_sorted_kernel, dim3(gblocks), dim3(256), 0, stream, a.chunk_records, a.chunk_counts, chunk_offsets, block_sums,
-                       a.total_chunks, a.cap, dense);
+                       a.total_chunks, a.cap, a.chunks_per_buf, dense);
     return hipGetLastError();
 }
 
