@@ -66,7 +66,8 @@ typedef struct adsb_amd_record
     int8_t   errorbit; /* -1, or the repaired bit (FixSingleBitErrors) */
     uint8_t  df;       /* msg[0]>>3 as sliced (before repair) -- Message::msgtype */
     uint8_t  flags;    /* ADSB_AMD_F_* */
-    uint8_t  msg[14];  /* message bytes after repair */
+    uint8_t  msg[14];  /* message bytes after repair; bytes beyond nbits/8 are 0 (the reference keeps sliced noise there
+                          and never reads it) */
 } adsb_amd_record_t;
 
 /* Accepted frame + aircraft snapshot handed to the callback (mirrors what IListener::OnChanged sees). */

@@ -167,6 +167,7 @@ __device__ __forceinline__ uint32_t chain_resolve(uint64_t cst, uint64_t val, ui
 }
 
 constexpr uint64_t kMask48 = (1ull << 48) - 1ull;
+constexpr uint64_t kMask56 = (1ull << 56) - 1ull;
 
 // 112 sliced bits from per-lane decisions: bit b keeps the value of the last decided bit <= b (:838).
 // Fast path (every bit decided, the normal case for a real frame): the value ballots are the message.
@@ -262,6 +263,11 @@ __device__ __forceinline__ void classify_and_emit(Emit& e, int lane, const LaneT
     const bool is17 = (df == 11 || df == 17);
     if (!is17 && !df_is_ap(df)) return; // BruteForceAp returns 0 for every other DF (:403-409)
 
+    if (nbits == 56)
+    { // a short frame keeps only its 56 bits: what the slicer produced beyond them is noise nothing downstream reads
+        ba &= kMask56;
+        bb = 0;
+    }
     const bool bit_a = (ba >> lane) & 1ull;
     const bool bit_b = (lane < 48) && ((bb >> lane) & 1ull);
     uint32_t   contrib, stored;
@@ -309,6 +315,49 @@ struct BitMags
 {
     int loA, hiA, loB, hiB;
 };
+
+// The common case, straight-line: a clean DF11/DF17 frame whose every relevant bit is far above the "decided" and
+// energy thresholds and whose parity checks.  Then the sliced bits are simply "which half is larger" (an exact
+// comparison of s), the reference accepts the frame on the first pass and nothing else about the candidate matters.
+// Returns true when the candidate is finished (record emitted, or provably dead); false hands it, untouched, to the
+// general demodulator below.
+__device__ __forceinline__ bool demod_clean_frame(const uint16_t* tile, int lane, const LaneTables& lt, Emit& e, int w0, uint32_t j)
+{
+    const bool     has_b = lane < 48;
+    const int      ia    = w0 + 16 + 2 * lane;
+    const int      ib    = has_b ? ia + 128 : ia;
+    const uint32_t sLoA = tile[ia], sHiA = tile[ia + 1], sLoB = tile[ib], sHiB = tile[ib + 1];
+    if (__builtin_amdgcn_readfirstlane((int)(sLoA == sHiA))) return true; // :839-846, dead on both passes
+    const float    fA = __builtin_fabsf(mag_estimate(sLoA) - mag_estimate(sHiA));
+    const float    fB = __builtin_fabsf(mag_estimate(sLoB) - mag_estimate(sHiB));
+    const uint64_t strongA = ballot(fA >= 2560.0f), strongB = ballot(has_b && fB >= 2560.0f);
+    const uint64_t valA = ballot(sLoA > sHiA), valB = ballot(has_b && sLoB > sHiB);
+    const uint32_t df   = (uint32_t)(__builtin_bitreverse64(valA) >> 59);
+    if (df != 11 && df != 17) return false;
+    uint64_t ba, bb;
+    uint32_t contrib, stored, nbits;
+    if (df == 17)
+    {
+        if (strongA != ~0ull || strongB != kMask48) return false;
+        ba      = valA;
+        bb      = valB;
+        nbits   = 112;
+        contrib = (((ba >> lane) & 1ull) ? lt.crc_a : 0u) ^ ((has_b && ((bb >> lane) & 1ull)) ? lt.crc_b : 0u);
+        stored  = (uint32_t)(__builtin_bitreverse64(bb) >> 16) & 0xFFFFFFu;
+    }
+    else
+    {
+        if ((strongA & kMask56) != kMask56) return false;
+        ba      = valA & kMask56;
+        bb      = 0;
+        nbits   = 56;
+        contrib = (((ba >> lane) & 1ull) && lane < 56) ? lt.crc_s : 0u;
+        stored  = (uint32_t)(__builtin_bitreverse64(ba) >> 8) & 0xFFFFFFu;
+    }
+    if ((wave_xor(contrib) ^ stored) != 0) return false; // needs repair or the retry: general path
+    emit_raw(e, lane, j, ba, bb, df, nbits, -1, 0u, 0u);
+    return true;
+}
 
 // Demodulate the candidate whose preamble starts at tile index w0 (sample j of the buffer).
 //
@@ -699,7 +748,8 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
             for (uint32_t t = 0; t < n2; t++)
             {
                 const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)queue[t]);
-                demod_candidate(tile, lane, lt, e, kFront + (int)pos, cur.g0 + pos);
+                if ((a.tune & 1u) || !demod_clean_frame(tile, lane, lt, e, kFront + (int)pos, cur.g0 + pos))
+                    demod_candidate(tile, lane, lt, e, kFront + (int)pos, cur.g0 + pos);
             }
             wave_lds_fence();
         }

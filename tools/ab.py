@@ -1,0 +1,38 @@
+"""In-process A/B of kernel variants selected by environment knobs (read per submit): interleaved rounds, median kernel ms.
+
+    python tools/ab.py "ADSB_AMD_TUNE=0" "ADSB_AMD_TUNE=1" ...
+"""
+import os
+import sys
+import statistics
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import libadsb_amd as A  # noqa: E402
+from libadsb_amd import synth  # noqa: E402
+
+variants = [dict(kv.split("=") for kv in v.split(",") if kv) for v in sys.argv[1:]] or [{}]
+BB = A.REF_BUFFER_BYTES
+nbuf = 4096
+iq, _ = synth.fill_range(0, nbuf, nthreads=16)
+d = torch.from_numpy(iq).cuda()
+torch.cuda.synchronize()
+sc = A.Scanner(0)
+st = torch.cuda.current_stream().cuda_stream
+keys = sorted({k for v in variants for k in v})
+res = [[] for _ in variants]
+nrec = [0] * len(variants)
+for rnd in range(7):
+    for i, v in enumerate(variants):
+        for k in keys:
+            os.environ.pop(k, None)
+        os.environ.update(v)
+        for _ in range(3):
+            sc.submit(d.data_ptr(), d.numel(), BB, st, 0)
+            r = sc.fetch(0, copy=False)
+            nrec[i] = len(r)
+            if rnd:
+                res[i].append(sc.timing(0)[0])
+for v, r, n in zip(variants, res, nrec):
+    print("%-40s kernel_ms median %.4f min %.4f  (records %d)" % (v, statistics.median(r), min(r), n))
