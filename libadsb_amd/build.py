@@ -16,8 +16,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libadsb_amd.so")
 SYNTH = os.path.join(HERE, "libadsb_synth.so")
 
-HIP_SOURCES = ["scan1090.hip", "capi.cpp", "resolver1090.cpp"]
-HIP_DEPS = HIP_SOURCES + ["scan1090.h", "resolver1090.hpp", os.path.join(ROOT, "include", "adsb_amd.h")]
+HIP_SOURCES = ["scan1090.hip", "capi.cpp", "resolver1090.cpp", "adsb1090_gpu_handler.cpp"]
+HIP_DEPS = HIP_SOURCES + ["scan1090.h", "resolver1090.hpp", os.path.join(ROOT, "include", "adsb_amd.h"),
+                           os.path.join(ROOT, "include", "libadsb_iface.hpp")]
 
 
 def _stale(target, deps):
@@ -31,7 +32,7 @@ def build_hip(force=False, verbose=False):
     if not force and not _stale(LIB, HIP_DEPS):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared", "-Wall", "-Wextra",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in HIP_SOURCES]
     if verbose:
         print(" ".join(cmd))
@@ -47,8 +48,23 @@ def build_synth(force=False):
     return SYNTH
 
 
+CXX_TEST = os.path.join(ROOT, "tests", "cpp", "test_1090_gpu")
+
+
+def build_cxx_test(force=False):
+    """The C++ drop-in test driver (uses the reference-shaped factories exported by libadsb_amd.so)."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_1090_gpu.cpp")
+    if not force and not _stale(CXX_TEST, [src, LIB, os.path.join(ROOT, "include", "libadsb_iface.hpp")]):
+        return CXX_TEST
+    subprocess.check_call(["g++", "-std=c++20", "-O2", "-I" + os.path.join(ROOT, "include"), "-o", CXX_TEST, src,
+                           "-L" + HERE, "-ladsb_amd", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"])
+    return CXX_TEST
+
+
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_synth(force)
+    libs = build_hip(force, verbose), build_synth(force)
+    build_cxx_test(force)
+    return libs
 
 
 if __name__ == "__main__":

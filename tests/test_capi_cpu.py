@@ -102,3 +102,11 @@ def test_decode_known_frames_through_resolver(native_libs):
                 got = got.decode()
                 got = got.ljust(8)
             assert got == want, (v["hex"], k, got, want)
+
+
+def test_cxx_factories_are_exported(native_libs):
+    # the two factories libadsb's callers bind (reference ADSB.h:13-15, 24-26), same namespaces and signatures
+    import subprocess
+    syms = subprocess.run(["nm", "-DC", native_libs[0]], capture_output=True, text=True).stdout
+    assert "ADSB::TryCreateADSB1090Handler(std::shared_ptr<ADSB::TrafficManager> const&, RTLSDR::IDeviceSelector const*, ADSB::Source)" in syms
+    assert "ADSB::test::TryCreateADSB1090Handler(std::shared_ptr<ADSB::TrafficManager> const&, RTLSDR::IDeviceSelector const*, ADSB::Source)" in syms

@@ -154,3 +154,23 @@ def test_async_two_slot_pipeline(scanner):
     H.assert_records_equal(r1, scanner.scan(iq1, BB))
     k_ms, t_ms = scanner.timing(1)
     assert 0 < k_ms <= t_ms
+
+
+def test_cxx_drop_in_handler_matches_reference_test_flow(native_libs, tmp_path):
+    # the reference's own test shape (tests/test_1090.cpp): C++ listener, ADSB::test::TryCreateADSB1090Handler, HandleData,
+    # one formatted line per OnChanged; here against the oracle's callback text instead of the (input-less) goldens
+    import subprocess
+    from libadsb_amd import build
+    exe = build.build_cxx_test()
+    iq, _ = synth.fill_range(200, 6)
+    path = tmp_path / "iq1090.bin"
+    iq.tofile(path)
+    for bb in (BB, 0):
+        out = subprocess.run([exe, str(path), str(bb)], capture_output=True, timeout=120)
+        assert out.returncode == 0, out.stderr.decode()
+        got = [l for l in out.stdout.split(b"\n") if l and not l.startswith(b"/opt/amdgpu")]
+        o = O.Oracle1090(sample_clock_hz=0)  # wall clock, like the C++ handler and the reference
+        _, oac = H.oracle_run(iq, bb, oracle=o)
+        want = [t.encode("latin-1") for t in H.callback_text(oac)]
+        assert got == want
+        assert len(got) > 100
