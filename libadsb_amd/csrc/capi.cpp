@@ -23,7 +23,6 @@ thread_local std::string g_create_error;
 struct Slot
 {
     uint32_t*          counts   = nullptr; // per chunk
-    uint32_t*          offsets  = nullptr;
     uint32_t*          block_sums = nullptr; // one per 1024 chunks
     adsb_amd_record_t* regions  = nullptr; // total_chunks * cap
     adsb_amd_record_t* dense    = nullptr;
@@ -78,11 +77,10 @@ constexpr uint32_t kDefaultCap = 32;
 void free_slot(Slot& s)
 {
     if (s.counts) (void)hipFree(s.counts);
-    if (s.offsets) (void)hipFree(s.offsets);
     if (s.block_sums) (void)hipFree(s.block_sums);
     if (s.regions) (void)hipFree(s.regions);
     if (s.dense) (void)hipFree(s.dense);
-    s.counts = s.offsets = s.block_sums = nullptr;
+    s.counts = s.block_sums = nullptr;
     s.regions = s.dense = nullptr;
     s.chunks_cap = s.cap_per_chunk = 0;
 }
@@ -93,7 +91,6 @@ int ensure_slot(adsb_amd_ctx* c, Slot& s, size_t chunks, size_t cap)
     free_slot(s);
     size_t nch = chunks ? chunks : 1;
     HIP_TRY(c, hipMalloc(&s.counts, nch * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc(&s.offsets, nch * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc(&s.block_sums, ((nch + 1023) / 1024) * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc(&s.regions, nch * cap * sizeof(adsb_amd_record_t)));
     HIP_TRY(c, hipMalloc(&s.dense, nch * cap * sizeof(adsb_amd_record_t)));
@@ -148,7 +145,7 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     s.args.chunk_counts  = s.counts;
     s.args.cap           = (uint32_t)s.cap_per_chunk;
     HIP_TRY(c, hipEventRecord(s.ev_begin, s.stream));
-    HIP_TRY(c, launch_scan1090(s.args, s.dense, s.offsets, s.block_sums, s.total_d, s.stream, s.ev_scan0, s.ev_scan1));
+    HIP_TRY(c, launch_scan1090(s.args, s.dense, s.block_sums, s.total_d, s.stream, s.ev_scan0, s.ev_scan1));
     HIP_TRY(c, hipMemcpyAsync(s.total_h, s.total_d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(c, hipEventRecord(s.ev_done, s.stream));
     return ADSB_AMD_OK;

@@ -56,12 +56,14 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u
 // int16 is just 0xFF00 | I'.  Cheap bit ops, two packed int16 MADs and one saturating packed add per pair of samples.
 __device__ __forceinline__ uint32_t iq2_to_s2(uint32_t x)
 {
+    // bitop3 truth tables, index = S0*4 + S1*2 + S2:  0x0C = ~S0 & S1,  0xAE = (~S0 & S1) | S2
+    const uint32_t m = 0x00FF00FFu, k = 0xFF00FF00u;
     const uint32_t y  = x >> 8;
-    const uint32_t ni = ~x & 0x00FF00FFu, hi = ni | 0xFF00FF00u;
-    const uint32_t nq = ~y & 0x00FF00FFu, hq = nq | 0xFF00FF00u;
-    const i16x2    k  = {16384, 16384};
-    const i16x2    a  = __builtin_bit_cast(i16x2, ni) * __builtin_bit_cast(i16x2, hi) + k; // (I-127)^2 in [0, 16384]
-    const i16x2    b  = __builtin_bit_cast(i16x2, nq) * __builtin_bit_cast(i16x2, hq) + k; // (Q-127)^2
+    const uint32_t ni = __builtin_amdgcn_bitop3_b32(x, m, m, 0x0C), hi = __builtin_amdgcn_bitop3_b32(x, m, k, 0xAE);
+    const uint32_t nq = __builtin_amdgcn_bitop3_b32(y, m, m, 0x0C), hq = __builtin_amdgcn_bitop3_b32(y, m, k, 0xAE);
+    const i16x2    c  = {16384, 16384};
+    const i16x2    a  = __builtin_bit_cast(i16x2, ni) * __builtin_bit_cast(i16x2, hi) + c; // (I-127)^2 in [0, 16384]
+    const i16x2    b  = __builtin_bit_cast(i16x2, nq) * __builtin_bit_cast(i16x2, hq) + c; // (Q-127)^2
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(a, b));
 }
 
@@ -333,29 +335,17 @@ __device__ __forceinline__ bool demod_clean_frame(const uint16_t* tile, int lane
     const uint64_t strongA = ballot(fA >= 2560.0f), strongB = ballot(has_b && fB >= 2560.0f);
     const uint64_t valA = ballot(sLoA > sHiA), valB = ballot(has_b && sLoB > sHiB);
     const uint32_t df   = (uint32_t)(__builtin_bitreverse64(valA) >> 59);
-    if (df != 11 && df != 17) return false;
-    uint64_t ba, bb;
-    uint32_t contrib, stored, nbits;
-    if (df == 17)
-    {
-        if (strongA != ~0ull || strongB != kMask48) return false;
-        ba      = valA;
-        bb      = valB;
-        nbits   = 112;
-        contrib = (((ba >> lane) & 1ull) ? lt.crc_a : 0u) ^ ((has_b && ((bb >> lane) & 1ull)) ? lt.crc_b : 0u);
-        stored  = (uint32_t)(__builtin_bitreverse64(bb) >> 16) & 0xFFFFFFu;
-    }
-    else
-    {
-        if ((strongA & kMask56) != kMask56) return false;
-        ba      = valA & kMask56;
-        bb      = 0;
-        nbits   = 56;
-        contrib = (((ba >> lane) & 1ull) && lane < 56) ? lt.crc_s : 0u;
-        stored  = (uint32_t)(__builtin_bitreverse64(ba) >> 8) & 0xFFFFFFu;
-    }
-    if ((wave_xor(contrib) ^ stored) != 0) return false; // needs repair or the retry: general path
-    emit_raw(e, lane, j, ba, bb, df, nbits, -1, 0u, 0u);
+    // everything below is selected, not branched, on the (wave-uniform) frame length: one exit decides
+    const bool     is_long = (df == 17);
+    const uint64_t ba      = is_long ? valA : (valA & kMask56);
+    const uint64_t bb      = is_long ? valB : 0ull;
+    const bool     strong  = is_long ? (strongA == ~0ull && strongB == kMask48) : ((strongA & kMask56) == kMask56);
+    const uint32_t tab_a   = is_long ? lt.crc_a : lt.crc_s; // crc_s is 0 on lanes >= 56
+    const uint32_t contrib = (((ba >> lane) & 1ull) ? tab_a : 0u) ^ ((has_b && ((bb >> lane) & 1ull)) ? lt.crc_b : 0u);
+    const uint32_t stored  = is_long ? ((uint32_t)(__builtin_bitreverse64(bb) >> 16) & 0xFFFFFFu) : ((uint32_t)(__builtin_bitreverse64(ba) >> 8) & 0xFFFFFFu);
+    const uint32_t syn     = wave_xor(contrib) ^ stored;
+    if (!((df == 17 || df == 11) && strong && syn == 0)) return false; // repair, retry, AP-type or weak bits: general path
+    emit_raw(e, lane, j, ba, bb, df, is_long ? 112u : 56u, -1, 0u, 0u);
     return true;
 }
 
@@ -563,13 +553,14 @@ __device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWin
     if (lane == 0 && g.g0 > 0) r.front = *reinterpret_cast<const uint16_t*>(g.buf + 2ull * (g.g0 - 1));
 }
 
-__global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
+__global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow)
 {
     __shared__ __attribute__((aligned(16))) uint16_t tile[kTileU16];
     __shared__ uint16_t                              queue[kQueueCap];
 
     const int        lane = threadIdx.x;
     const LaneTables lt   = load_lane_tables(a.crc_tab, lane);
+    if (blockIdx.x == 0 && lane < 2) total_overflow[lane] = 0; // {record total, overflow flag}: filled by the ordering pass that follows in-stream
 
     // XCD-aware chunk order: workgroups b and b+8 share an XCD (round-robin dispatch), so give every XCD one
     // contiguous range of chunks and let its workgroups walk that range together -> halo re-reads hit its L2.
@@ -661,7 +652,7 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
             uint32_t m2o[10]; // (max(s[2i+1],s[2i+2]), max(s[2i+2],s[2i+3]))
 #pragma unroll
             for (int i = 1; i <= 9; i++) m2o[i] = pk_max(p1[i], p0[i + 1]);
-            uint32_t bits = 0;
+            uint32_t ok[8]; // sign bit of each half set <=> the position passes all ten comparisons
 #pragma unroll
             for (int i = 0; i < 8; i++)
             {
@@ -672,14 +663,29 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a)
                 const uint32_t d2   = pk_sub(pk_max(p1[i], p1[i + 1]), p0[i + 1]);     // max(m1,m3) < m2
                 const uint32_t d3   = pk_sub(p0[i + 4], pk_min(p1[i + 3], p1[i + 4])); // m8 < min(m7,m9)
                 const uint32_t d4   = pk_sub(p0[i + 3], p1[i + 4]);                    // m6 < m9
-                const uint32_t ok   = (d1 & d2 & d3 & d4) & 0x80008000u;
-                bits |= ((ok >> 15) | (ok >> 30)) << (2 * i); // bit 15 -> 0, bit 31 -> 1 (stray high bits masked below)
+                ok[i]               = d1 & d2 & d3 & d4;
             }
-            bits &= 0xFFFFu;
-            const int first_pos = sr * 1024 + 16 * lane;
-            const int nvalid    = (int)cur.npos - first_pos;
-            if (nvalid < 16) bits &= (nvalid <= 0) ? 0u : ((1u << nvalid) - 1u);
+            // movemask: gather the two sign-carrying bytes of each word (v_perm), then one multiply pulls the four MSBs
+            // of a dword together:  ((x & 0x80808080) * 0x00204081) >> 28  =  b0 | b1<<1 | b2<<2 | b3<<3
+            uint32_t bits = 0;
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+            {
+                const uint32_t x = __builtin_amdgcn_perm(ok[2 * g + 1], ok[2 * g], 0x07050301u) & 0x80808080u;
+                bits |= ((x * 0x00204081u) >> 28) << (4 * g);
+            }
             surv |= (uint64_t)bits << (16 * sr);
+        }
+        if (cur.npos < (uint32_t)kChunk)
+        { // last chunk of a buffer: positions at or beyond N-240 do not exist (ADSB1090.cpp:772)
+            const int base = 16 * lane;
+#pragma unroll
+            for (int sr = 0; sr < kChunk / 1024; sr++)
+            {
+                const int nvalid = (int)cur.npos - (sr * 1024 + base);
+                uint64_t  keep   = (nvalid >= 16) ? 0xFFFFull : (nvalid <= 0 ? 0ull : ((1ull << nvalid) - 1ull));
+                surv &= ~(0xFFFFull << (16 * sr)) | (keep << (16 * sr));
+            }
         }
 
         if (a.phase_limit == 2)
@@ -783,10 +789,9 @@ __device__ __forceinline__ uint32_t block_incl_scan_1024(uint32_t v, uint32_t* w
     return x + basev;
 }
 
-// offsets[c] = exclusive prefix inside its 1024-chunk block; block_sums[b] = block total
-__global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                           uint32_t* __restrict__ block_sums, uint32_t nchunks, uint32_t cap,
-                                                           uint32_t* __restrict__ total_overflow)
+// block_sums[b] = number of records of chunks [1024 b, 1024 (b+1)), each chunk clamped to its region size
+__global__ __launch_bounds__(1024) void block_sums_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ block_sums,
+                                                          uint32_t nchunks, uint32_t cap, uint32_t* __restrict__ total_overflow)
 {
     __shared__ uint32_t wave_tot[16];
     const uint32_t      c = blockIdx.x * 1024u + threadIdx.x;
@@ -796,85 +801,77 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t* __res
         v = cap;
         atomicOr(&total_overflow[1], 1u);
     }
-    uint32_t       tot;
-    const uint32_t incl = block_incl_scan_1024(v, wave_tot, &tot);
-    if (c < nchunks) offsets[c] = incl - v;
+    uint32_t tot;
+    (void)block_incl_scan_1024(v, wave_tot, &tot);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
-
-// block_sums -> exclusive prefix in place (one workgroup), total_overflow[0] = number of records
-__global__ __launch_bounds__(1024) void scan_top_kernel(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t* __restrict__ total_overflow)
-{
-    __shared__ uint32_t wave_tot[16];
-    uint32_t            carry = 0;
-    for (uint32_t b0 = 0; b0 < nblocks; b0 += 1024u)
-    {
-        const uint32_t b = b0 + threadIdx.x;
-        const uint32_t v = (b < nblocks) ? block_sums[b] : 0u;
-        uint32_t       tot;
-        const uint32_t incl = block_incl_scan_1024(v, wave_tot, &tot);
-        if (b < nblocks) block_sums[b] = carry + incl - v;
-        carry += tot;
-    }
-    if (threadIdx.x == 0) total_overflow[0] = carry;
 }
 
 // reverse the bit order inside each byte: message bit n (n = 8k + b, b = 0 first/MSB) -> bit 7-b of byte k
 __device__ __forceinline__ uint32_t msg_bytes(uint32_t bits) { return __builtin_bswap32(__builtin_bitreverse32(bits)); }
 
-__global__ __launch_bounds__(256) void gather_sorted_kernel(const adsb_amd_record_t* __restrict__ chunk_records,
-                                                            const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                            const uint32_t* __restrict__ block_base, uint32_t nchunks, uint32_t cap,
-                                                            uint32_t chunks_per_buf, adsb_amd_record_t* __restrict__ dense)
+// One workgroup per 1024 chunks, one thread per chunk: position of the chunk's records in the dense array = records of all
+// earlier blocks (summed here from block_sums) + exclusive prefix inside the block; then the thread copies its chunk's
+// few records in (offset, pass) order, turning each raw record into the public adsb_amd_record_t (repair flip, byte
+// order, address).
+__global__ __launch_bounds__(1024) void gather_sorted_kernel(const adsb_amd_record_t* __restrict__ chunk_records,
+                                                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ block_sums,
+                                                             uint32_t nchunks, uint32_t nblocks, uint32_t cap, uint32_t chunks_per_buf,
+                                                             adsb_amd_record_t* __restrict__ dense, uint32_t* __restrict__ total_overflow)
 {
-    const int      lane   = threadIdx.x & 63;
-    const uint32_t wave   = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t c = wave; c < nchunks; c += nwaves)
+    __shared__ uint32_t wave_tot[16];
+    // records in earlier blocks
+    uint32_t before = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 1024u) before += block_sums[b];
+    uint32_t base;
+    (void)block_incl_scan_1024(before, wave_tot, &base);
+
+    const uint32_t c = blockIdx.x * 1024u + threadIdx.x;
+    uint32_t       n = (c < nchunks) ? counts[c] : 0u;
+    if (n > cap) n = cap;
+    uint32_t       tot;
+    const uint32_t incl = block_incl_scan_1024(n, wave_tot, &tot);
+    if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) total_overflow[0] = base + tot;
+    if (n == 0) return;
+
+    const uint4*       src    = reinterpret_cast<const uint4*>(chunk_records + (uint64_t)c * cap);
+    adsb_amd_record_t* dst    = dense + (base + incl - n);
+    const uint32_t     buffer = c / chunks_per_buf;
+    for (uint32_t i = 0; i < n; i++)
     {
-        uint32_t n = counts[c];
-        if (n == 0) continue;
-        if (n > cap) n = cap;
-        const uint4*       src = reinterpret_cast<const uint4*>(chunk_records + (uint64_t)c * cap);
-        adsb_amd_record_t* dst = dense + (block_base[c >> 10] + offsets[c]);
-        const uint32_t     buffer = c / chunks_per_buf;
-        for (uint32_t i = (uint32_t)lane; i < n; i += 64)
+        const uint4    lo   = src[2 * i];
+        uint4          hi   = src[2 * i + 1];
+        const uint32_t key  = (lo.x << 1) | ((lo.y >> 16) & 1u); // (offset, pass)
+        uint32_t       rank = 0;
+        for (uint32_t k = 0; k < n; k++)
         {
-            const uint4    lo   = src[2 * i];
-            uint4          hi   = src[2 * i + 1];
-            const uint32_t key  = (lo.x << 1) | ((lo.y >> 16) & 1u); // (offset, pass)
-            uint32_t       rank = 0;
-            for (uint32_t k = 0; k < n; k++)
-            {
-                const uint4 q = src[2 * k];
-                rank += (((q.x << 1) | ((q.y >> 16) & 1u)) < key) ? 1u : 0u;
-            }
-            // raw -> adsb_amd_record_t: apply the 1-bit repair, order the bytes, pull the address out
-            const uint32_t df = lo.y & 0xFFu, nbits = (lo.y >> 8) & 0xFFu, flags = (lo.y >> 16) & 0xFFu;
-            const int      errorbit = (int)(lo.y >> 24) - 1;
-            if (errorbit >= 0)
-            {
-                const uint32_t m = 1u << (errorbit & 31);
-                if (errorbit < 32) hi.x ^= m;
-                else if (errorbit < 64) hi.y ^= m;
-                else if (errorbit < 96) hi.z ^= m;
-                else hi.w ^= m;
-            }
-            const uint32_t m0 = msg_bytes(hi.x), m1 = msg_bytes(hi.y), m2 = msg_bytes(hi.z), m3 = msg_bytes(hi.w); // bytes 0-3, 4-7, 8-11, 12-13
-            const uint32_t addr = (flags & ADSB_AMD_F_NEEDS_ICAO) ? lo.z : (((m0 >> 8) & 0xFFu) << 16 | ((m0 >> 16) & 0xFFu) << 8 | (m0 >> 24));
-            uint4 o0, o1;
-            o0.x = buffer;
-            o0.y = lo.x;
-            o0.z = addr;
-            o0.w = (nbits << 16) | (((uint32_t)errorbit & 0xFFu) << 24);
-            o1.x = df | (flags << 8) | (m0 << 16);
-            o1.y = (m0 >> 16) | (m1 << 16);
-            o1.z = (m1 >> 16) | (m2 << 16);
-            o1.w = (m2 >> 16) | (m3 << 16);
-            uint4* o = reinterpret_cast<uint4*>(dst + rank);
-            o[0]     = o0;
-            o[1]     = o1;
+            const uint4 q = src[2 * k];
+            rank += (((q.x << 1) | ((q.y >> 16) & 1u)) < key) ? 1u : 0u;
         }
+        // raw -> adsb_amd_record_t: apply the 1-bit repair, order the bytes, pull the address out
+        const uint32_t df = lo.y & 0xFFu, nbits = (lo.y >> 8) & 0xFFu, flags = (lo.y >> 16) & 0xFFu;
+        const int      errorbit = (int)(lo.y >> 24) - 1;
+        if (errorbit >= 0)
+        {
+            const uint32_t m = 1u << (errorbit & 31);
+            if (errorbit < 32) hi.x ^= m;
+            else if (errorbit < 64) hi.y ^= m;
+            else if (errorbit < 96) hi.z ^= m;
+            else hi.w ^= m;
+        }
+        const uint32_t m0 = msg_bytes(hi.x), m1 = msg_bytes(hi.y), m2 = msg_bytes(hi.z), m3 = msg_bytes(hi.w); // bytes 0-3, 4-7, 8-11, 12-13
+        const uint32_t addr = (flags & ADSB_AMD_F_NEEDS_ICAO) ? lo.z : (((m0 >> 8) & 0xFFu) << 16 | ((m0 >> 16) & 0xFFu) << 8 | (m0 >> 24));
+        uint4 o0, o1;
+        o0.x = buffer;
+        o0.y = lo.x;
+        o0.z = addr;
+        o0.w = (nbits << 16) | (((uint32_t)errorbit & 0xFFu) << 24);
+        o1.x = df | (flags << 8) | (m0 << 16);
+        o1.y = (m0 >> 16) | (m1 << 16);
+        o1.z = (m1 >> 16) | (m2 << 16);
+        o1.w = (m2 >> 16) | (m3 << 16);
+        uint4* o = reinterpret_cast<uint4*>(dst + rank);
+        o[0]     = o0;
+        o[1]     = o1;
     }
 }
 
@@ -907,25 +904,21 @@ __global__ __launch_bounds__(256) void phase978_kernel(const uint8_t* __restrict
 
 } // namespace
 
-hipError_t launch_scan1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t* chunk_offsets, uint32_t* block_sums,
-                           uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t ev_scan_begin, hipEvent_t ev_scan_end)
+hipError_t launch_scan1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t* block_sums, uint32_t* total_and_overflow, hipStream_t stream,
+                           hipEvent_t ev_scan_begin, hipEvent_t ev_scan_end)
 {
-    hipError_t err = hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
-    if (err != hipSuccess || a.total_chunks == 0) return err;
+    if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
     // persistent single-wave workgroups: enough to fill 256 CUs at the LDS-limited occupancy (16 per CU), multiple of 8 (XCDs)
     uint32_t grid = 256u * 16u;
     if (grid > a.total_chunks) grid = ((a.total_chunks + 7u) / 8u) * 8u;
     if (ev_scan_begin) (void)hipEventRecord(ev_scan_begin, stream);
-    hipLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
     if (ev_scan_end) (void)hipEventRecord(ev_scan_end, stream);
     const uint32_t nblocks = (a.total_chunks + 1023u) / 1024u;
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(nblocks), dim3(1024), 0, stream, a.chunk_counts, chunk_offsets, block_sums, a.total_chunks,
-                       a.cap, total_and_overflow);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, block_sums, nblocks, total_and_overflow);
-    uint32_t gblocks = (a.total_chunks + 3u) / 4u;
-    if (gblocks > 4096u) gblocks = 4096u;
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3(gblocks), dim3(256), 0, stream, a.chunk_records, a.chunk_counts, chunk_offsets, block_sums,
-                       a.total_chunks, a.cap, a.chunks_per_buf, dense);
+    hipLaunchKernelGGL(block_sums_kernel, dim3(nblocks), dim3(1024), 0, stream, a.chunk_counts, block_sums, a.total_chunks, a.cap,
+                       total_and_overflow);
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(1024), 0, stream, a.chunk_records, a.chunk_counts, block_sums, a.total_chunks,
+                       nblocks, a.cap, a.chunks_per_buf, dense, total_and_overflow);
     return hipGetLastError();
 }
 

@@ -13,12 +13,22 @@ import libadsb_amd as A  # noqa: E402
 from libadsb_amd import synth  # noqa: E402
 
 variants = [dict(kv.split("=") for kv in v.split(",") if kv) for v in sys.argv[1:]] or [{}]
+# a variant may name its own build of the library: lib=ab_libs/foo.so (see tools/build_variant.sh)
 BB = A.REF_BUFFER_BYTES
 nbuf = 4096
 iq, _ = synth.fill_range(0, nbuf, nthreads=16)
 d = torch.from_numpy(iq).cuda()
 torch.cuda.synchronize()
-sc = A.Scanner(0)
+import ctypes as C
+scanners = {}
+def scanner_for(v):
+    path = v.get("lib")
+    if path not in scanners:
+        if path:
+            A._lib = None
+            A.LIB_PATH = os.path.abspath(path)
+        scanners[path] = A.Scanner(0)
+    return scanners[path]
 st = torch.cuda.current_stream().cuda_stream
 keys = sorted({k for v in variants for k in v})
 res = [[] for _ in variants]
@@ -27,7 +37,8 @@ for rnd in range(7):
     for i, v in enumerate(variants):
         for k in keys:
             os.environ.pop(k, None)
-        os.environ.update(v)
+        os.environ.update({k: x for k, x in v.items() if k != "lib"})
+        sc = scanner_for(v)
         for _ in range(3):
             sc.submit(d.data_ptr(), d.numel(), BB, st, 0)
             r = sc.fetch(0, copy=False)
