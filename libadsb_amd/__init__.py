@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadsb_amd.so")
+LIB_PATH = os.environ.get("ADSB_AMD_LIB") or os.path.join(_HERE, "libadsb_amd.so")  # override: A/B of build variants only
 
 REF_BUFFER_BYTES = 262144
 F_PASS2, F_PHASE, F_NEEDS_ICAO = 1, 2, 4

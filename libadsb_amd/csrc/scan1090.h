@@ -14,7 +14,10 @@ namespace adsb_amd
 // of one reference buffer out of an LDS-staged window of kChunk + kHalo samples.
 constexpr int kLanes      = 64;
 constexpr int kRowSamples = 512; // one 16-byte load per lane = 8 IQ samples per lane = 512 per wavefront
-constexpr int kRows       = 8;
+#ifndef ADSB_AMD_ROWS
+#define ADSB_AMD_ROWS 8
+#endif
+constexpr int kRows       = ADSB_AMD_ROWS; // 1 KiB load rows per chunk (even: stage 1 walks 1024-position super-rows)
 constexpr int kChunk      = kRows * kRowSamples; // 4096 positions
 constexpr int kHalo       = 256;                 // >= 240 samples read past the last position, half a row
 constexpr int kFront      = 8;                   // u16 slots before the window; slot 7 = sample g0-1

@@ -52,19 +52,18 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u
 // Two IQ samples (4 bytes I0 Q0 I1 Q1) -> (s0 | s1 << 16), s = (I-127)^2 + (Q-127)^2 saturated to 32767.
 // 32768 (I = Q = 255) is the only value above 32767 and 32767 itself is not a sum of two squares, so the
 // saturation keeps the order of all reachable values and makes every difference fit in an int16.
-// With I' = 255 - I (a bitwise NOT of the byte): (I-127)^2 = (I'-128)^2 = I' * (I' - 256) + 16384, and I' - 256 as an
-// int16 is just 0xFF00 | I'.  Cheap bit ops, two packed int16 MADs and one saturating packed add per pair of samples.
+// Six VALU ops per pair of samples: two byte permutes unpack I and Q into 16-bit halves, two packed subtracts remove the
+// 127 offset, one packed multiply and one saturating packed multiply-add (signed clamp = 32767) finish.
 __device__ __forceinline__ uint32_t iq2_to_s2(uint32_t x)
 {
-    // bitop3 truth tables, index = S0*4 + S1*2 + S2:  0x0C = ~S0 & S1,  0xAE = (~S0 & S1) | S2
-    const uint32_t m = 0x00FF00FFu, k = 0xFF00FF00u;
-    const uint32_t y  = x >> 8;
-    const uint32_t ni = __builtin_amdgcn_bitop3_b32(x, m, m, 0x0C), hi = __builtin_amdgcn_bitop3_b32(x, m, k, 0xAE);
-    const uint32_t nq = __builtin_amdgcn_bitop3_b32(y, m, m, 0x0C), hq = __builtin_amdgcn_bitop3_b32(y, m, k, 0xAE);
-    const i16x2    c  = {16384, 16384};
-    const i16x2    a  = __builtin_bit_cast(i16x2, ni) * __builtin_bit_cast(i16x2, hi) + c; // (I-127)^2 in [0, 16384]
-    const i16x2    b  = __builtin_bit_cast(i16x2, nq) * __builtin_bit_cast(i16x2, hq) + c; // (Q-127)^2
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(a, b));
+    const uint32_t i16 = __builtin_amdgcn_perm(0u, x, 0x0C020C00u); // (I0, I1): bytes 0 and 2, zero-extended (selector 0x0C = 0x00)
+    const uint32_t q16 = __builtin_amdgcn_perm(0u, x, 0x0C030C01u); // (Q0, Q1): bytes 1 and 3
+    const u16x2    c   = {127, 127};
+    const uint32_t di  = as_u32(as_pk(i16) - c), dq = as_u32(as_pk(q16) - c);
+    const uint32_t a   = as_u32(as_pk(di) * as_pk(di)); // (I-127)^2 <= 16384, exact modulo 2^16
+    uint32_t       r;
+    asm("v_pk_mad_i16 %0, %1, %1, %2 clamp" : "=v"(r) : "v"(dq), "v"(a));
+    return r;
 }
 
 __device__ __forceinline__ uint32_t iq1_to_s(uint32_t i, uint32_t q)
@@ -318,35 +317,64 @@ struct BitMags
     int loA, hiA, loB, hiB;
 };
 
-// The common case, straight-line: a clean DF11/DF17 frame whose every relevant bit is far above the "decided" and
-// energy thresholds and whose parity checks.  Then the sliced bits are simply "which half is larger" (an exact
-// comparison of s), the reference accepts the frame on the first pass and nothing else about the candidate matters.
-// Returns true when the candidate is finished (record emitted, or provably dead); false hands it, untouched, to the
-// general demodulator below.
-__device__ __forceinline__ bool demod_clean_frame(const uint16_t* tile, int lane, const LaneTables& lt, Emit& e, int w0, uint32_t j)
+// DetectOutOfPhase (:683-690) != 0 for the preamble at tile index w0 (j >= 1): needs exact magnitudes of m[j-1 .. j+10].
+__device__ __forceinline__ bool preamble_out_of_phase(const uint16_t* tile, int lane, int w0)
+{
+    const int pre = mag_of_s(tile[w0 - 1 + (lane & 15)]); // lanes 0..15: m[j-1 .. j+14]
+    const int m_1 = __builtin_amdgcn_readlane(pre, 0), m1 = __builtin_amdgcn_readlane(pre, 2), m2 = __builtin_amdgcn_readlane(pre, 3);
+    const int m3 = __builtin_amdgcn_readlane(pre, 4), m6 = __builtin_amdgcn_readlane(pre, 7), m7 = __builtin_amdgcn_readlane(pre, 8);
+    const int m9 = __builtin_amdgcn_readlane(pre, 10), m10 = __builtin_amdgcn_readlane(pre, 11);
+    // x > y/3 (integer division)  <=>  3x > y
+    return (3 * m3 > m2) || (3 * m10 > m9) || (3 * m6 > m7) || (3 * m_1 > m1);
+}
+
+// The common case, nearly straight-line: a frame whose every relevant bit is far above the "decided" and energy
+// thresholds.  Then the sliced bits are simply "which half is larger" (an exact comparison of s) and pass 1 is settled
+// here: DF11/17 with good parity or a single repairable bit is accepted by the reference on the spot; an AP-type DF
+// yields its conditional record and, unless the preamble is out of phase, the retry would reproduce the same bits.
+// Returns 0 when the candidate is finished, 1 when the general demodulator has to run from scratch (nothing was
+// emitted), 2 when only its retry pass remains (the pass-1 record is already out).
+__device__ __forceinline__ int demod_strong_frame(const uint16_t* tile, int lane, const LaneTables& lt, Emit& e, int w0, uint32_t j)
 {
     const bool     has_b = lane < 48;
     const int      ia    = w0 + 16 + 2 * lane;
     const int      ib    = has_b ? ia + 128 : ia;
     const uint32_t sLoA = tile[ia], sHiA = tile[ia + 1], sLoB = tile[ib], sHiB = tile[ib + 1];
-    if (__builtin_amdgcn_readfirstlane((int)(sLoA == sHiA))) return true; // :839-846, dead on both passes
+    if (__builtin_amdgcn_readfirstlane((int)(sLoA == sHiA))) return 0; // :839-846, dead on both passes
     const float    fA = __builtin_fabsf(mag_estimate(sLoA) - mag_estimate(sHiA));
     const float    fB = __builtin_fabsf(mag_estimate(sLoB) - mag_estimate(sHiB));
     const uint64_t strongA = ballot(fA >= 2560.0f), strongB = ballot(has_b && fB >= 2560.0f);
     const uint64_t valA = ballot(sLoA > sHiA), valB = ballot(has_b && sLoB > sHiB);
     const uint32_t df   = (uint32_t)(__builtin_bitreverse64(valA) >> 59);
-    // everything below is selected, not branched, on the (wave-uniform) frame length: one exit decides
-    const bool     is_long = (df == 17);
+    // everything below is selected, not branched, on the (wave-uniform) frame length
+    const bool     is_long = df_is_long(df);
+    const bool     is17    = (df == 17 || df == 11);
     const uint64_t ba      = is_long ? valA : (valA & kMask56);
     const uint64_t bb      = is_long ? valB : 0ull;
     const bool     strong  = is_long ? (strongA == ~0ull && strongB == kMask48) : ((strongA & kMask56) == kMask56);
+    if (!strong || !(is17 || df_is_ap(df))) return 1;
+    const uint32_t nbits   = is_long ? 112u : 56u;
     const uint32_t tab_a   = is_long ? lt.crc_a : lt.crc_s; // crc_s is 0 on lanes >= 56
     const uint32_t contrib = (((ba >> lane) & 1ull) ? tab_a : 0u) ^ ((has_b && ((bb >> lane) & 1ull)) ? lt.crc_b : 0u);
     const uint32_t stored  = is_long ? ((uint32_t)(__builtin_bitreverse64(bb) >> 16) & 0xFFFFFFu) : ((uint32_t)(__builtin_bitreverse64(ba) >> 8) & 0xFFFFFFu);
     const uint32_t syn     = wave_xor(contrib) ^ stored;
-    if (!((df == 17 || df == 11) && strong && syn == 0)) return false; // repair, retry, AP-type or weak bits: general path
-    emit_raw(e, lane, j, ba, bb, df, is_long ? 112u : 56u, -1, 0u, 0u);
-    return true;
+    if (is17)
+    {
+        int errorbit = -1;
+        if (syn != 0)
+        { // FixSingleBitErrors (:304-332): first bit whose flip makes stored == computed
+            const uint64_t ma = is_long ? ballot(syn == lt.syn_a) : ballot(lane < 56 && syn == lt.syn_s);
+            const uint64_t mb = is_long ? ballot(has_b && syn == lt.syn_b) : 0ull;
+            if (ma) errorbit = __builtin_ctzll(ma);
+            else if (mb) errorbit = 64 + __builtin_ctzll(mb);
+            else return 1; // not repairable: the reference retries with phase correction
+        }
+        emit_raw(e, lane, j, ba, bb, df, nbits, errorbit, 0u, 0u);
+        return 0;
+    }
+    emit_raw(e, lane, j, ba, bb, df, nbits, -1, ADSB_AMD_F_NEEDS_ICAO, syn);
+    if (j == 0 || !preamble_out_of_phase(tile, lane, w0)) return 0; // the retry would slice the same window again
+    return 2;
 }
 
 // Demodulate the candidate whose preamble starts at tile index w0 (sample j of the buffer).
@@ -356,7 +384,7 @@ __device__ __forceinline__ bool demod_clean_frame(const uint16_t* tile, int lane
 // the estimates whenever they are further from their thresholds than the estimate's error bound.  Only when some
 // decision is inside that margin -- or the retry slice, which rescales exact magnitudes, is needed -- are the exact
 // magnitudes computed.  Either way the bits that come out are exactly the reference's.
-__device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, const LaneTables& lt, Emit& e, int w0, uint32_t j)
+__device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, const LaneTables& lt, Emit& e, int w0, uint32_t j, bool pass1_done)
 {
     const bool has_b = lane < 48;
     // bit `lane` lives in samples j+16+2*lane, j+17+2*lane; bit 64+lane another 128 samples on (ADSB1090.cpp:831-835)
@@ -374,6 +402,8 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
     uint32_t   sum56 = 0, sumrest = 0;
     uint64_t   ba = 0, bb = 0;
     uint32_t   df = 0, nbits = 0;
+    bool       stateless = false;
+    if (!pass1_done)
     {
         // ---------------- pass 1 on estimates
         const float fA = __builtin_fabsf(mag_estimate(sLoA) - mag_estimate(sHiA));
@@ -419,21 +449,11 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
             const uint32_t delta = (nbits == 112u) ? (sum56 + sumrest) / 56u : sum56 / 28u;
             if (delta < 2550u) return; // :877-881, no retry either
         }
+        classify_and_emit(e, lane, lt, ba, bb, df, nbits, j, 0u, &stateless);
+        if (stateless) return; // the reference accepts here and never retries
+        // ---------------- pass 2: retry with phase correction (:814-826); identical to pass 1 unless the window is rescaled
+        if (j == 0 || !preamble_out_of_phase(tile, lane, w0)) return;
     }
-    bool stateless = false;
-    classify_and_emit(e, lane, lt, ba, bb, df, nbits, j, 0u, &stateless);
-    if (stateless) return; // the reference accepts here and never retries
-
-    // ---------------- pass 2: retry with phase correction (:814-826); identical to pass 1 unless the window is rescaled
-    if (j == 0) return;
-    // preamble neighbourhood m[j-1 .. j+14] on lanes 0..15 (DetectOutOfPhase :683-690)
-    const int pre = mag_of_s(tile[w0 - 1 + (lane & 15)]);
-    const int m_1 = __builtin_amdgcn_readlane(pre, 0), m1 = __builtin_amdgcn_readlane(pre, 2), m2 = __builtin_amdgcn_readlane(pre, 3);
-    const int m3 = __builtin_amdgcn_readlane(pre, 4), m6 = __builtin_amdgcn_readlane(pre, 7), m7 = __builtin_amdgcn_readlane(pre, 8);
-    const int m9 = __builtin_amdgcn_readlane(pre, 10), m10 = __builtin_amdgcn_readlane(pre, 11);
-    // x > y/3 (integer division)  <=>  3x > y
-    const bool oop = (3 * m3 > m2) || (3 * m10 > m9) || (3 * m6 > m7) || (3 * m_1 > m1);
-    if (!oop) return;
     if (!have_exact)
     {
         x.loA = mag_of_s(sLoA); x.hiA = mag_of_s(sHiA); x.loB = mag_of_s(sLoB); x.hiB = mag_of_s(sHiB);
@@ -553,7 +573,10 @@ __device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWin
     if (lane == 0 && g.g0 > 0) r.front = *reinterpret_cast<const uint16_t*>(g.buf + 2ull * (g.g0 - 1));
 }
 
-__global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow)
+#ifndef ADSB_AMD_MIN_WAVES
+#define ADSB_AMD_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow)
 {
     __shared__ __attribute__((aligned(16))) uint16_t tile[kTileU16];
     __shared__ uint16_t                              queue[kQueueCap];
@@ -611,6 +634,7 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a, uint32_t* __re
         const ChunkGeom cur  = g;
         const uint32_t  me   = chunk;
         const uint32_t  next = chunk + nslot;
+#ifndef ADSB_AMD_NO_PREFETCH
         if (next < end)
         {
             bidx += step_b;
@@ -623,13 +647,16 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a, uint32_t* __re
             g = chunk_geom(a, bidx, cidx);
             load_window(g, lane, raw);
         }
+#endif
         wave_lds_fence();
+#ifndef ADSB_AMD_NO_PREFETCH
         if (a.phase_limit == 1)
         {
             if (next >= end) break;
             chunk = next;
             continue;
         }
+#endif
 
         // ---------------- stage 1 on packed s.  A lane takes 16 consecutive positions (pairs (2i, 2i+1), i = 0..7) of a
         // 1024-position super-row, so the 9-sample look-ahead is amortised over twice as many positions.
@@ -646,9 +673,22 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a, uint32_t* __re
             p0[4] = q1.x; p0[5] = q1.y; p0[6] = q1.z; p0[7] = q1.w;
             p0[8] = q2.x; p0[9] = q2.y; p0[10] = q2.z; p0[11] = q2.w;
             p0[12] = *reinterpret_cast<const uint32_t*>(&tile[w + 24]);
-            uint32_t p1[12]; // odd-aligned pairs (s[2i+1], s[2i+2])
+            uint32_t p1[12]; // odd-aligned pairs (s[2i+1], s[2i+2]), funnel-shifted out of p0.  (Reading them from LDS at a 2-byte
+                             // offset works on gfx950 but measured 3.7 % slower: misaligned ds_read_b128 is split.)
+#ifndef ADSB_AMD_P1_LDS_UNALIGNED
 #pragma unroll
             for (int i = 0; i < 12; i++) p1[i] = __builtin_amdgcn_alignbit(p0[i + 1], p0[i], 16);
+#else
+            {
+                typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
+                const u32x4_u r0 = *reinterpret_cast<const u32x4_u*>(&tile[w + 1]);
+                const u32x4_u r1 = *reinterpret_cast<const u32x4_u*>(&tile[w + 9]);
+                const u32x4_u r2 = *reinterpret_cast<const u32x4_u*>(&tile[w + 17]);
+                p1[0] = r0.x; p1[1] = r0.y; p1[2] = r0.z; p1[3] = r0.w;
+                p1[4] = r1.x; p1[5] = r1.y; p1[6] = r1.z; p1[7] = r1.w;
+                p1[8] = r2.x; p1[9] = r2.y; p1[10] = r2.z; p1[11] = r2.w;
+            }
+#endif
             uint32_t m2o[10]; // (max(s[2i+1],s[2i+2]), max(s[2i+2],s[2i+3]))
 #pragma unroll
             for (int i = 1; i <= 9; i++) m2o[i] = pk_max(p1[i], p0[i + 1]);
@@ -675,6 +715,25 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a, uint32_t* __re
                 bits |= ((x * 0x00204081u) >> 28) << (4 * g);
             }
             surv |= (uint64_t)bits << (16 * sr);
+#if defined(ADSB_AMD_PAD_CHEAP) || defined(ADSB_AMD_PAD_PK) || defined(ADSB_AMD_PAD_SALU)
+            { // calibration only: N extra independent instructions of one class per super-row (never in a shipped build)
+                uint32_t t0 = p0[0], t1 = p0[1], t2 = p0[2], t3 = p0[3];
+                uint32_t u0 = (uint32_t)sr;
+#ifdef ADSB_AMD_PAD_CHEAP
+#pragma unroll
+                for (int z = 0; z < ADSB_AMD_PAD_CHEAP / 4; z++) { asm volatile("v_and_b32 %0, %0, %4\n v_and_b32 %1, %1, %4\n v_and_b32 %2, %2, %4\n v_and_b32 %3, %3, %4" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(p0[5])); }
+#endif
+#ifdef ADSB_AMD_PAD_PK
+#pragma unroll
+                for (int z = 0; z < ADSB_AMD_PAD_PK / 4; z++) { asm volatile("v_pk_max_u16 %0, %0, %4\n v_pk_max_u16 %1, %1, %4\n v_pk_max_u16 %2, %2, %4\n v_pk_max_u16 %3, %3, %4" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(p0[5])); }
+#endif
+#ifdef ADSB_AMD_PAD_SALU
+#pragma unroll
+                for (int z = 0; z < ADSB_AMD_PAD_SALU / 4; z++) { asm volatile("s_add_u32 %0, %0, 3\n s_add_u32 %0, %0, 5\n s_add_u32 %0, %0, 7\n s_add_u32 %0, %0, 9" : "+s"(u0) : : "scc"); }
+#endif
+                if ((t0 ^ t1 ^ t2 ^ t3 ^ u0) == 0x12345677u) surv ^= 1; // keep the padding alive
+            }
+#endif
         }
         if (cur.npos < (uint32_t)kChunk)
         { // last chunk of a buffer: positions at or beyond N-240 do not exist (ADSB1090.cpp:772)
@@ -688,6 +747,7 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a, uint32_t* __re
             }
         }
 
+#ifndef ADSB_AMD_NO_PREFETCH
         if (a.phase_limit == 2)
         {
             if (lane == 0) a.chunk_counts[me] = (uint32_t)(surv != 0) & 0u;
@@ -695,6 +755,7 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a, uint32_t* __re
             chunk = next;
             continue;
         }
+#endif
 
         // ---------------- survivors -> queue -> stage 2 -> demod, at most kQueueCap survivors per pass
         const uint32_t mine = (uint32_t)__builtin_popcountll(surv);
@@ -754,8 +815,8 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a, uint32_t* __re
             for (uint32_t t = 0; t < n2; t++)
             {
                 const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)queue[t]);
-                if ((a.tune & 1u) || !demod_clean_frame(tile, lane, lt, e, kFront + (int)pos, cur.g0 + pos))
-                    demod_candidate(tile, lane, lt, e, kFront + (int)pos, cur.g0 + pos);
+                const int todo = (a.tune & 1u) ? 1 : demod_strong_frame(tile, lane, lt, e, kFront + (int)pos, cur.g0 + pos);
+                if (todo) demod_candidate(tile, lane, lt, e, kFront + (int)pos, cur.g0 + pos, todo == 2);
             }
             wave_lds_fence();
         }
@@ -763,6 +824,17 @@ __global__ __launch_bounds__(64) void scan1090_kernel(ScanArgs a, uint32_t* __re
 
         if (next >= end) break;
         chunk = next;
+#ifdef ADSB_AMD_NO_PREFETCH
+        bidx += step_b;
+        cidx += step_c;
+        if (cidx >= a.chunks_per_buf)
+        {
+            cidx -= a.chunks_per_buf;
+            bidx++;
+        }
+        g = chunk_geom(a, bidx, cidx);
+        load_window(g, lane, raw);
+#endif
     }
 }
 
@@ -909,7 +981,10 @@ hipError_t launch_scan1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t
 {
     if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
     // persistent single-wave workgroups: enough to fill 256 CUs at the LDS-limited occupancy (16 per CU), multiple of 8 (XCDs)
-    uint32_t grid = 256u * 16u;
+#ifndef ADSB_AMD_WAVES_PER_CU
+#define ADSB_AMD_WAVES_PER_CU 16
+#endif
+    uint32_t grid = 256u * ADSB_AMD_WAVES_PER_CU;
     if (grid > a.total_chunks) grid = ((a.total_chunks + 7u) / 8u) * 8u;
     if (ev_scan_begin) (void)hipEventRecord(ev_scan_begin, stream);
     hipLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);

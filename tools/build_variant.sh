@@ -7,5 +7,5 @@ if [ "$rev" = "WORK" ]; then cp -r $root/libadsb_amd/csrc $tmp/csrc; cp -r $root
 else mkdir -p $tmp/csrc $tmp/include; (cd $root && git archive $rev libadsb_amd/csrc include | tar -x -C $tmp); mv $tmp/libadsb_amd/csrc/* $tmp/csrc/; fi
 srcs="$tmp/csrc/scan1090.hip $tmp/csrc/capi.cpp $tmp/csrc/resolver1090.cpp"
 [ -f $tmp/csrc/adsb1090_gpu_handler.cpp ] && srcs="$srcs $tmp/csrc/adsb1090_gpu_handler.cpp"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -shared -I$tmp/include -I$tmp/csrc -o $root/ab_libs/$name.so $srcs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -shared $EXTRA_FLAGS -I$tmp/include -I$tmp/csrc -o $root/ab_libs/$name.so $srcs
 rm -rf $tmp; echo built ab_libs/$name.so
