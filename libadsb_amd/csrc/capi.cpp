@@ -144,8 +144,13 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     s.args.chunk_records = s.regions;
     s.args.chunk_counts  = s.counts;
     s.args.cap           = (uint32_t)s.cap_per_chunk;
+    // Everything on the caller's stream.  (Running the ordering pass on a second stream beside the next scan was
+    // measured slower: its workgroups take CU slots from the persistent scan waves and the scan grows a tail.)
     HIP_TRY(c, hipEventRecord(s.ev_begin, s.stream));
-    HIP_TRY(c, launch_scan1090(s.args, s.dense, s.block_sums, s.total_d, s.stream, s.ev_scan0, s.ev_scan1));
+    HIP_TRY(c, hipEventRecord(s.ev_scan0, s.stream));
+    HIP_TRY(c, launch_scan1090(s.args, s.total_d, s.stream));
+    HIP_TRY(c, hipEventRecord(s.ev_scan1, s.stream));
+    HIP_TRY(c, launch_order1090(s.args, s.dense, s.block_sums, s.total_d, s.stream));
     HIP_TRY(c, hipMemcpyAsync(s.total_h, s.total_d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(c, hipEventRecord(s.ev_done, s.stream));
     return ADSB_AMD_OK;

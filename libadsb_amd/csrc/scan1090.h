@@ -48,11 +48,12 @@ inline uint32_t chunks_per_buffer(uint32_t buf_samples)
     return (positions + (uint32_t)kChunk - 1) / (uint32_t)kChunk;
 }
 
-// Enqueue: demodulation kernel, then the ordering pass (per-block record sums, then the sorted gather into `dense`).
-// `total_and_overflow` is a device uint32_t[2]: {number of records in dense, overflow flag}; `block_sums` holds one
-// uint32_t per 1024 chunks.
-hipError_t launch_scan1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t* block_sums, uint32_t* total_and_overflow, hipStream_t stream,
-                           hipEvent_t ev_scan_begin, hipEvent_t ev_scan_end);
+// Demodulation kernel (fills the per-chunk record regions and counts; zeroes `total_and_overflow`).
+hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream);
+// Ordering pass: per-block record sums, then the sorted gather into `dense`.  `total_and_overflow` is a device
+// uint32_t[2]: {number of records in dense, overflow flag}; `block_sums` holds one uint32_t per 1024 chunks.  It only
+// touches records, so it may run on another stream beside the next scan.
+hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t* block_sums, uint32_t* total_and_overflow, hipStream_t stream);
 
 // magnitudes exactly as the reference computes them (parity helper)
 hipError_t launch_magnitude1090(const uint8_t* iq, uint16_t* mag, size_t nsamples, hipStream_t stream);

@@ -76,15 +76,13 @@ __device__ __forceinline__ uint32_t iq1_to_s(uint32_t i, uint32_t q)
 // Exact reference magnitude round(sqrt(s) * 360) (ADSB1090.cpp:138) from the saturated s.
 __device__ __forceinline__ int mag_of_s(uint32_t s)
 {
-    const uint32_t se = s + ((s + 1u) >> 15); // 32767 stands for 32768
-    const float    f  = __builtin_amdgcn_sqrtf((float)se);
-    uint32_t       m  = (uint32_t)__builtin_fmaf(f, 360.0f, 0.5f);
-    const uint32_t t  = __umul24(se, 129600u);          // < 2^32
-    const int      d  = (int)(t - __umul24(m, m));      // m <= 65168: exact in 32 bits
-    const int      mi = (int)m;
-    m += (d > mi) ? 1u : 0u;        // 129600 s >  m^2 + m : estimate one too small
-    m -= (d + mi <= 0) ? 1u : 0u;   // 129600 s <= m^2 - m : estimate one too large
-    return se ? (int)m : 0;
+    const float    f = __builtin_amdgcn_sqrtf((float)s);
+    const int      m = (int)(uint32_t)__builtin_fmaf(f, 360.0f, 0.5f);
+    const uint32_t t = __umul24(s, 129600u);                  // < 2^32
+    const int      d = (int)(t - (uint32_t)__umul24(m, m));   // m <= 65167: exact in 32 bits
+    // 129600 s > m^2 + m: estimate one too small;  129600 s <= m^2 - m: one too large (max() keeps s = 0 at 0)
+    const int      r = __builtin_elementwise_max(m + (d > m ? 1 : 0) - (d + m <= 0 ? 1 : 0), 0);
+    return (s == 32767u) ? 65167 : r;                          // 32767 stands for s = 32768 (I = Q = 255)
 }
 
 // Float estimate of the same magnitude: |est - 360*sqrt(s)| < 0.05 (v_sqrt_f32 is good to 1 ulp, one more rounding in
@@ -692,7 +690,10 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
             uint32_t m2o[10]; // (max(s[2i+1],s[2i+2]), max(s[2i+2],s[2i+3]))
 #pragma unroll
             for (int i = 1; i <= 9; i++) m2o[i] = pk_max(p1[i], p0[i + 1]);
-            uint32_t ok[8]; // sign bit of each half set <=> the position passes all ten comparisons
+            // Sign bit of each half of d1&d2&d3&d4 set <=> that position passes all ten comparisons.  Movemask by dot product:
+            // with the flags isolated at bits 15 and 31, dot2(flags, (2^(2i), 2^(2i+1))) adds 2^(15+2i) and 2^(16+2i), so
+            // the eight pairs accumulate into bits 15..30 of one register, one VALU op per pair.
+            uint32_t acc = 0;
 #pragma unroll
             for (int i = 0; i < 8; i++)
             {
@@ -703,17 +704,11 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
                 const uint32_t d2   = pk_sub(pk_max(p1[i], p1[i + 1]), p0[i + 1]);     // max(m1,m3) < m2
                 const uint32_t d3   = pk_sub(p0[i + 4], pk_min(p1[i + 3], p1[i + 4])); // m8 < min(m7,m9)
                 const uint32_t d4   = pk_sub(p0[i + 3], p1[i + 4]);                    // m6 < m9
-                ok[i]               = d1 & d2 & d3 & d4;
+                const uint32_t ok   = (d1 & d2 & d3 & d4) & 0x80008000u;
+                const u16x2    wt   = {(unsigned short)(1u << (2 * i)), (unsigned short)(2u << (2 * i))};
+                acc                 = __builtin_amdgcn_udot2(as_pk(ok), wt, acc, false);
             }
-            // movemask: gather the two sign-carrying bytes of each word (v_perm), then one multiply pulls the four MSBs
-            // of a dword together:  ((x & 0x80808080) * 0x00204081) >> 28  =  b0 | b1<<1 | b2<<2 | b3<<3
-            uint32_t bits = 0;
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-            {
-                const uint32_t x = __builtin_amdgcn_perm(ok[2 * g + 1], ok[2 * g], 0x07050301u) & 0x80808080u;
-                bits |= ((x * 0x00204081u) >> 28) << (4 * g);
-            }
+            const uint32_t bits = acc >> 15;
             surv |= (uint64_t)bits << (16 * sr);
 #if defined(ADSB_AMD_PAD_CHEAP) || defined(ADSB_AMD_PAD_PK) || defined(ADSB_AMD_PAD_SALU)
             { // calibration only: N extra independent instructions of one class per super-row (never in a shipped build)
@@ -976,8 +971,7 @@ __global__ __launch_bounds__(256) void phase978_kernel(const uint8_t* __restrict
 
 } // namespace
 
-hipError_t launch_scan1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t* block_sums, uint32_t* total_and_overflow, hipStream_t stream,
-                           hipEvent_t ev_scan_begin, hipEvent_t ev_scan_end)
+hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream)
 {
     if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
     // persistent single-wave workgroups: enough to fill 256 CUs at the LDS-limited occupancy (16 per CU), multiple of 8 (XCDs)
@@ -986,9 +980,13 @@ hipError_t launch_scan1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t
 #endif
     uint32_t grid = 256u * ADSB_AMD_WAVES_PER_CU;
     if (grid > a.total_chunks) grid = ((a.total_chunks + 7u) / 8u) * 8u;
-    if (ev_scan_begin) (void)hipEventRecord(ev_scan_begin, stream);
     hipLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
-    if (ev_scan_end) (void)hipEventRecord(ev_scan_end, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t* block_sums, uint32_t* total_and_overflow, hipStream_t stream)
+{
+    if (a.total_chunks == 0) return hipSuccess;
     const uint32_t nblocks = (a.total_chunks + 1023u) / 1024u;
     hipLaunchKernelGGL(block_sums_kernel, dim3(nblocks), dim3(1024), 0, stream, a.chunk_counts, block_sums, a.total_chunks, a.cap,
                        total_and_overflow);
