@@ -25,6 +25,17 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def measured_traffic(bytes_per_gpu):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json:
+    FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc runs of this same workload); None when no matching entry."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        e = t.get(str(bytes_per_gpu))
+        return int(e["traffic_bytes"]) if e else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(iq_host, nbuf_sample, buffer_bytes):
     """The CPU restatement (oracle) timed on this host: 1 thread over a bounded sample of the same buffers."""
     from oracle import oracle_py as O
@@ -68,6 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mib", type=int, default=1024, help="MiB of u8 IQ per GPU (weak scaling)")
     ap.add_argument("--cpu-buffers", type=int, default=4096, help="reference buffers in the CPU-baseline sample (0: skip)")
+    ap.add_argument("--serial", action="store_true", help="submit/fetch one step at a time (no overlap of the record copy with the next "
+                    "scan); used for rocprofv3 runs, where the runtime's shader-based copy would otherwise co-run with the scan kernel")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,6 +116,14 @@ def main():
         """`steps` pipelined steps; returns (records of the last step, sum of scan-kernel ms, sum of enqueue-to-count ms)."""
         k_ms = t_ms = 0.0
         rec = None
+        if args.serial:
+            for i in range(steps):
+                sc.submit(d_iq.data_ptr(), nbytes, BB, stream, 0)
+                rec = sc.fetch(0, copy=False)
+                a, b = sc.timing(0)
+                k_ms += a
+                t_ms += b
+            return rec, k_ms, t_ms
         sc.submit(d_iq.data_ptr(), nbytes, BB, stream, 0)
         for i in range(1, steps):
             sc.submit(d_iq.data_ptr(), nbytes, BB, stream, i & 1)
@@ -162,9 +183,10 @@ def main():
                                    "0x1090AD5B, noise +-3, ~1 frame / 2000 samples), fused magnitude + preamble gates + Manchester slice + "
                                    "phase retry + CRC-24 + 1-bit repair; reference demodulates 2 samples/us (2.0 MS/s, SURVEY.md F5)"
                                    % (args.mib, nbuf),
-                       "bytes_per_gpu": nbytes, "buffers_per_gpu": nbuf, "sharding": "contiguous buffer ranges, no data-path collective"},
+                       "bytes_per_gpu": nbytes, "buffers_per_gpu": nbuf, "sharding": "contiguous buffer ranges, no data-path collective",
+                       "pipelined": not args.serial},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(nbytes),
                          "kernel": "scan1090_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes": int(alg_bytes)},
             "records_per_step": nrec_all, "frames_injected": injected_all,
