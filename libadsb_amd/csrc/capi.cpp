@@ -23,7 +23,7 @@ thread_local std::string g_create_error;
 struct Slot
 {
     uint32_t*          counts   = nullptr; // per chunk
-    uint32_t*          block_sums = nullptr; // one per 1024 chunks
+    uint32_t*          block_sums = nullptr; // one per 256 chunks
     adsb_amd_record_t* regions  = nullptr; // total_chunks * cap
     adsb_amd_record_t* dense    = nullptr;
     uint32_t*          total_d  = nullptr; // device {total, overflow}
@@ -91,7 +91,7 @@ int ensure_slot(adsb_amd_ctx* c, Slot& s, size_t chunks, size_t cap)
     free_slot(s);
     size_t nch = chunks ? chunks : 1;
     HIP_TRY(c, hipMalloc(&s.counts, nch * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc(&s.block_sums, ((nch + 1023) / 1024) * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&s.block_sums, ((nch + 255) / 256) * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc(&s.regions, nch * cap * sizeof(adsb_amd_record_t)));
     HIP_TRY(c, hipMalloc(&s.dense, nch * cap * sizeof(adsb_amd_record_t)));
     s.chunks_cap    = nch;

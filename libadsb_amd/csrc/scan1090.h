@@ -51,7 +51,7 @@ inline uint32_t chunks_per_buffer(uint32_t buf_samples)
 // Demodulation kernel (fills the per-chunk record regions and counts; zeroes `total_and_overflow`).
 hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream);
 // Ordering pass: per-block record sums, then the sorted gather into `dense`.  `total_and_overflow` is a device
-// uint32_t[2]: {number of records in dense, overflow flag}; `block_sums` holds one uint32_t per 1024 chunks.  It only
+// uint32_t[2]: {number of records in dense, overflow flag}; `block_sums` holds one uint32_t per 256 chunks.  It only
 // touches records, so it may run on another stream beside the next scan.
 hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t* block_sums, uint32_t* total_and_overflow, hipStream_t stream);
 

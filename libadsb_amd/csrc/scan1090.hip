@@ -837,7 +837,10 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
 // ordering pass: exclusive prefix over the per-chunk counts (two small kernels), then one wave per chunk copies its
 // records into the dense array sorted by (offset, pass).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t block_incl_scan_1024(uint32_t v, uint32_t* wave_tot /* [16] shared */, uint32_t* block_total)
+constexpr uint32_t kOrderBlock = 256; // chunks per workgroup of the ordering pass
+
+// inclusive scan over a 256-thread workgroup (4 waves); *block_total receives the sum
+__device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t* wave_tot /* [4] shared */, uint32_t* block_total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t  x    = wave_incl_scan_add(v);
@@ -845,7 +848,7 @@ __device__ __forceinline__ uint32_t block_incl_scan_1024(uint32_t v, uint32_t* w
     __syncthreads();
     uint32_t basev = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++)
+    for (int w = 0; w < 4; w++)
     {
         const uint32_t t = wave_tot[w];
         if (w < wave) basev += t;
@@ -856,12 +859,12 @@ __device__ __forceinline__ uint32_t block_incl_scan_1024(uint32_t v, uint32_t* w
     return x + basev;
 }
 
-// block_sums[b] = number of records of chunks [1024 b, 1024 (b+1)), each chunk clamped to its region size
-__global__ __launch_bounds__(1024) void block_sums_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ block_sums,
-                                                          uint32_t nchunks, uint32_t cap, uint32_t* __restrict__ total_overflow)
+// block_sums[b] = number of records of chunks [256 b, 256 (b+1)), each chunk clamped to its region size
+__global__ __launch_bounds__(256) void block_sums_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ block_sums,
+                                                         uint32_t nchunks, uint32_t cap, uint32_t* __restrict__ total_overflow)
 {
-    __shared__ uint32_t wave_tot[16];
-    const uint32_t      c = blockIdx.x * 1024u + threadIdx.x;
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t      c = blockIdx.x * kOrderBlock + threadIdx.x;
     uint32_t            v = (c < nchunks) ? counts[c] : 0u;
     if (v > cap)
     {
@@ -869,34 +872,34 @@ __global__ __launch_bounds__(1024) void block_sums_kernel(const uint32_t* __rest
         atomicOr(&total_overflow[1], 1u);
     }
     uint32_t tot;
-    (void)block_incl_scan_1024(v, wave_tot, &tot);
+    (void)block_incl_scan_256(v, wave_tot, &tot);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
 // reverse the bit order inside each byte: message bit n (n = 8k + b, b = 0 first/MSB) -> bit 7-b of byte k
 __device__ __forceinline__ uint32_t msg_bytes(uint32_t bits) { return __builtin_bswap32(__builtin_bitreverse32(bits)); }
 
-// One workgroup per 1024 chunks, one thread per chunk: position of the chunk's records in the dense array = records of all
+// One workgroup per 256 chunks, one thread per chunk: position of the chunk's records in the dense array = records of all
 // earlier blocks (summed here from block_sums) + exclusive prefix inside the block; then the thread copies its chunk's
 // few records in (offset, pass) order, turning each raw record into the public adsb_amd_record_t (repair flip, byte
 // order, address).
-__global__ __launch_bounds__(1024) void gather_sorted_kernel(const adsb_amd_record_t* __restrict__ chunk_records,
-                                                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ block_sums,
-                                                             uint32_t nchunks, uint32_t nblocks, uint32_t cap, uint32_t chunks_per_buf,
-                                                             adsb_amd_record_t* __restrict__ dense, uint32_t* __restrict__ total_overflow)
+__global__ __launch_bounds__(256) void gather_sorted_kernel(const adsb_amd_record_t* __restrict__ chunk_records,
+                                                            const uint32_t* __restrict__ counts, const uint32_t* __restrict__ block_sums,
+                                                            uint32_t nchunks, uint32_t nblocks, uint32_t cap, uint32_t chunks_per_buf,
+                                                            adsb_amd_record_t* __restrict__ dense, uint32_t* __restrict__ total_overflow)
 {
-    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t wave_tot[4];
     // records in earlier blocks
     uint32_t before = 0;
-    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 1024u) before += block_sums[b];
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kOrderBlock) before += block_sums[b];
     uint32_t base;
-    (void)block_incl_scan_1024(before, wave_tot, &base);
+    (void)block_incl_scan_256(before, wave_tot, &base);
 
-    const uint32_t c = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t c = blockIdx.x * kOrderBlock + threadIdx.x;
     uint32_t       n = (c < nchunks) ? counts[c] : 0u;
     if (n > cap) n = cap;
     uint32_t       tot;
-    const uint32_t incl = block_incl_scan_1024(n, wave_tot, &tot);
+    const uint32_t incl = block_incl_scan_256(n, wave_tot, &tot);
     if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) total_overflow[0] = base + tot;
     if (n == 0) return;
 
@@ -987,10 +990,10 @@ hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipS
 hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t* block_sums, uint32_t* total_and_overflow, hipStream_t stream)
 {
     if (a.total_chunks == 0) return hipSuccess;
-    const uint32_t nblocks = (a.total_chunks + 1023u) / 1024u;
-    hipLaunchKernelGGL(block_sums_kernel, dim3(nblocks), dim3(1024), 0, stream, a.chunk_counts, block_sums, a.total_chunks, a.cap,
+    const uint32_t nblocks = (a.total_chunks + kOrderBlock - 1u) / kOrderBlock;
+    hipLaunchKernelGGL(block_sums_kernel, dim3(nblocks), dim3(kOrderBlock), 0, stream, a.chunk_counts, block_sums, a.total_chunks, a.cap,
                        total_and_overflow);
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(1024), 0, stream, a.chunk_records, a.chunk_counts, block_sums, a.total_chunks,
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderBlock), 0, stream, a.chunk_records, a.chunk_counts, block_sums, a.total_chunks,
                        nblocks, a.cap, a.chunks_per_buf, dense, total_and_overflow);
     return hipGetLastError();
 }
