@@ -162,6 +162,56 @@ void        adsb_amd_handler_set_sample_clock(adsb_amd_handler_t* h, int64_t t0_
 long adsb_amd_handler_handle_data(adsb_amd_handler_t* h, const uint8_t* iq_host, size_t nbytes, size_t buffer_bytes,
                                   adsb_amd_on_changed_fn cb, void* user);
 
+/* =====================================================================================================================
+ * UAT 978.  Boundary replaced:
+ *   UAT978Handler::HandleData(std::span<uint8_t const>)                     UAT978.cpp:43-60   -> adsb_amd_uat_handle_data
+ *   extern "C" void init_fec(); int process_buffer(uint16_t const*, int, uint64_t)   UAT978.cpp:9-10 -> same names, below
+ *   extern "C" void dump_raw_message(char, uint8_t*, int, int)               uat2json-wrapper.cpp:14 (the up-call, host's)
+ * The arithmetic behind process_buffer is the un-vendored dump978 module: this side restates the published
+ * legacy algorithm; parity unpinned (checked against oracle/oracle978.c only).
+ * Division of work: phases (LUT), sign of the phase difference, every 18-bit sync match, the 36-bit sync re-check and the
+ * frame slicing run on the GPU; Reed-Solomon and the order-dependent scan-loop rules run on the host.
+ * ===================================================================================================================*/
+typedef struct adsb_amd_uat adsb_amd_uat_t;
+
+/* dump_raw_message(updown, data, len, rs_errors) plus the stream sample index of the frame's first sync sample;
+ * updown '-' = ADS-B downlink (len 18 or 34), '+' = ground uplink (len 432) */
+typedef void (*adsb_amd_uat_frame_fn)(void* user, char updown, const uint8_t* data, int len, int rs_errors, uint64_t sample_index);
+typedef void (*adsb_amd_dump_raw_message_fn)(char updown, uint8_t* data, int len, int rs_errors);
+
+int         adsb_amd_uat_create(adsb_amd_uat_t** out, int device);
+void        adsb_amd_uat_destroy(adsb_amd_uat_t* u);
+const char* adsb_amd_uat_last_error(const adsb_amd_uat_t* u); /* u == NULL: error of the last failed create on this thread */
+
+/* UAT978Handler::HandleData: u8 IQ pairs in, staged 65 536 phases at a time exactly as UAT978.cpp:48-59 does, frames out
+ * through cb in stream order.  The reference passes the unconsumed tail's ENTRY count as memmove's BYTE count (:57), so only
+ * half of the tail really carries over; that is reproduced by default.  set_carry_full(1) carries the whole tail. */
+int adsb_amd_uat_handle_data(adsb_amd_uat_t* u, const uint8_t* iq_host, size_t nbytes, adsb_amd_uat_frame_fn cb, void* user);
+int adsb_amd_uat_set_carry_full(adsb_amd_uat_t* u, int full);
+int adsb_amd_uat_stream_state(const adsb_amd_uat_t* u, uint64_t* offset, size_t* used); /* UAT978Handler::offset / used */
+
+/* process_buffer over one buffer of any length < 2^31 samples (the reference passes <= 65 536): phases from the host, or u8
+ * IQ from the host / already in HBM (on_device != 0, 2-byte aligned).  *consumed = samples the caller may drop (negative
+ * when the buffer is shorter than one maximum frame, as in dump978). */
+int adsb_amd_uat_process_phases(adsb_amd_uat_t* u, const uint16_t* phi_host, uint64_t len, uint64_t offset, adsb_amd_uat_frame_fn cb, void* user,
+                                int64_t* consumed);
+int adsb_amd_uat_process_iq(adsb_amd_uat_t* u, const void* iq, uint64_t nsamples, int on_device, uint64_t offset, adsb_amd_uat_frame_fn cb,
+                            void* user, int64_t* consumed);
+/* device time of the last process call (sign+match kernels, demod kernel) and running totals of 18-bit matches and of
+ * positions the host had to ask the device about on top of those */
+int adsb_amd_uat_timing(const adsb_amd_uat_t* u, float* scan_ms, float* demod_ms, uint64_t* candidates, uint64_t* extra_lookups);
+int adsb_amd_uat_phase_lut(const adsb_amd_uat_t* u, uint16_t* lut65536);  /* InitATan2Table, UAT978.cpp:76-100 */
+int adsb_amd_uat_rs_decode(int kind, uint8_t* codeword); /* 0 RS(30,18), 1 RS(48,34), 2 RS(92,72); in place; corrected count or -1 */
+
+/* The reference's own seam, for a host that links this library instead of dump978's legacy objects.  init_fec() creates a
+ * process-wide context on device $ADSB_AMD_DEVICE (default 0) and aborts with a message when there is no usable GPU;
+ * process_buffer() reports frames through dump_raw_message (weakly bound: the host's definition, uat2json-wrapper.cpp:14)
+ * or through the function registered here. */
+void init_fec(void);
+int  process_buffer(const uint16_t* phi, int len, uint64_t offset);
+void adsb_amd_uat_set_dump_raw_message(adsb_amd_dump_raw_message_fn fn);
+
+
 #ifdef __cplusplus
 }
 #endif

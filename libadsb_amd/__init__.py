@@ -31,6 +31,9 @@ EXPORTS = [
     "adsb_amd_resolver_create", "adsb_amd_resolver_destroy", "adsb_amd_resolver_set_sample_clock", "adsb_amd_resolver_feed",
     "adsb_amd_resolver_aircraft_count", "adsb_amd_handler_create", "adsb_amd_handler_destroy", "adsb_amd_handler_last_error",
     "adsb_amd_handler_set_sample_clock", "adsb_amd_handler_handle_data",
+    "adsb_amd_uat_create", "adsb_amd_uat_destroy", "adsb_amd_uat_last_error", "adsb_amd_uat_handle_data", "adsb_amd_uat_set_carry_full",
+    "adsb_amd_uat_stream_state", "adsb_amd_uat_process_phases", "adsb_amd_uat_process_iq", "adsb_amd_uat_timing", "adsb_amd_uat_phase_lut",
+    "adsb_amd_uat_rs_decode", "adsb_amd_uat_set_dump_raw_message", "init_fec", "process_buffer",
 ]
 
 
@@ -78,6 +81,23 @@ def lib():
         L.adsb_amd_handler_set_sample_clock.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
         L.adsb_amd_handler_handle_data.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
         L.adsb_amd_handler_handle_data.restype = C.c_long
+        L.adsb_amd_uat_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.adsb_amd_uat_destroy.argtypes = [C.c_void_p]
+        L.adsb_amd_uat_last_error.argtypes = [C.c_void_p]
+        L.adsb_amd_uat_last_error.restype = C.c_char_p
+        L.adsb_amd_uat_handle_data.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.adsb_amd_uat_set_carry_full.argtypes = [C.c_void_p, C.c_int]
+        L.adsb_amd_uat_stream_state.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
+        L.adsb_amd_uat_process_phases.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.adsb_amd_uat_process_iq.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p,
+                                              C.POINTER(C.c_int64)]
+        L.adsb_amd_uat_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.adsb_amd_uat_phase_lut.argtypes = [C.c_void_p, C.c_void_p]
+        L.adsb_amd_uat_rs_decode.argtypes = [C.c_int, C.c_void_p]
+        L.adsb_amd_uat_set_dump_raw_message.argtypes = [C.c_void_p]
+        L.init_fec.restype = None
+        L.process_buffer.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        L.process_buffer.restype = C.c_int
         _lib = L
     return _lib
 
@@ -218,3 +238,89 @@ class Handler1090:
         if n < 0:
             raise AdsbAmdError("handle_data failed (%d): %s" % (n, self._l.adsb_amd_handler_last_error(self._h).decode()))
         return col.arrays()
+
+
+UAT_FRAME = C.CFUNCTYPE(None, C.c_void_p, C.c_char, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_uint64)
+DUMP_RAW_MESSAGE = C.CFUNCTYPE(None, C.c_char, C.POINTER(C.c_uint8), C.c_int, C.c_int)
+
+
+def rs_decode978(kind, codeword):
+    """The product's Reed-Solomon decoder (host code, no GPU): kind 0 RS(30,18), 1 RS(48,34), 2 RS(92,72).  Returns (count, bytes)."""
+    buf = np.array(np.frombuffer(bytes(codeword), dtype=np.uint8))
+    n = lib().adsb_amd_uat_rs_decode(kind, buf.ctypes.data)
+    return n, buf.tobytes()
+
+
+class Uat978:
+    """UAT 978 path (UAT978Handler / process_buffer).  Frames come back as (updown, payload bytes, rs_errors, sample_index)."""
+
+    def __init__(self, device=-1, carry_full=False):
+        self._l = lib()
+        self._h = C.c_void_p()
+        dev = int(os.environ.get("LOCAL_RANK", "0")) if device < 0 else device
+        rc = self._l.adsb_amd_uat_create(C.byref(self._h), dev)
+        if rc != 0:
+            self._h = None
+            raise AdsbAmdError("adsb_amd_uat_create failed (%d): %s" % (rc, self._l.adsb_amd_uat_last_error(None).decode()))
+        if carry_full:
+            self._l.adsb_amd_uat_set_carry_full(self._h, 1)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.adsb_amd_uat_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AdsbAmdError("libadsb_amd UAT error %d: %s" % (rc, self._l.adsb_amd_uat_last_error(self._h).decode()))
+
+    @staticmethod
+    def _collector(out):
+        def _cb(_u, updown, data, n, rs, idx):
+            out.append((updown.decode(), bytes(data[:n]), int(rs), int(idx)))
+        return UAT_FRAME(_cb)
+
+    def handle_data(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        out = []
+        cb = self._collector(out)
+        self._check(self._l.adsb_amd_uat_handle_data(self._h, iq.ctypes.data, iq.size, cb, None))
+        return out
+
+    def stream_state(self):
+        off, used = C.c_uint64(), C.c_size_t()
+        self._l.adsb_amd_uat_stream_state(self._h, C.byref(off), C.byref(used))
+        return off.value, used.value
+
+    def process_phases(self, phi, offset=0):
+        phi = np.ascontiguousarray(phi, dtype=np.uint16)
+        out, done = [], C.c_int64()
+        cb = self._collector(out)
+        self._check(self._l.adsb_amd_uat_process_phases(self._h, phi.ctypes.data, phi.size, offset, cb, None, C.byref(done)))
+        return out, done.value
+
+    def process_iq(self, iq, offset=0):
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        out, done = [], C.c_int64()
+        cb = self._collector(out)
+        self._check(self._l.adsb_amd_uat_process_iq(self._h, iq.ctypes.data, iq.size // 2, 0, offset, cb, None, C.byref(done)))
+        return out, done.value
+
+    def process_device(self, device_ptr, nsamples, offset=0, collect=True):
+        out, done = [], C.c_int64()
+        cb = self._collector(out) if collect else None
+        self._check(self._l.adsb_amd_uat_process_iq(self._h, C.c_void_p(device_ptr), nsamples, 1, offset, cb, None, C.byref(done)))
+        return out, done.value
+
+    def timing(self):
+        a, b, c, d = C.c_float(), C.c_float(), C.c_uint64(), C.c_uint64()
+        self._l.adsb_amd_uat_timing(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return {"scan_ms": a.value, "demod_ms": b.value, "candidates": c.value, "extra_lookups": d.value}
+
+    def phase_lut(self):
+        lut = np.empty(65536, dtype=np.uint16)
+        self._check(self._l.adsb_amd_uat_phase_lut(self._h, lut.ctypes.data))
+        return lut

@@ -16,8 +16,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libadsb_amd.so")
 SYNTH = os.path.join(HERE, "libadsb_synth.so")
 
-HIP_SOURCES = ["scan1090.hip", "capi.cpp", "resolver1090.cpp", "adsb1090_gpu_handler.cpp"]
-HIP_DEPS = HIP_SOURCES + ["scan1090.h", "resolver1090.hpp", os.path.join(ROOT, "include", "adsb_amd.h"),
+HIP_SOURCES = ["scan1090.hip", "uat978.hip", "capi.cpp", "resolver1090.cpp", "adsb1090_gpu_handler.cpp", "uat978_host.cpp"]
+HIP_DEPS = HIP_SOURCES + ["scan1090.h", "uat978.h", "resolver1090.hpp", os.path.join(ROOT, "include", "adsb_amd.h"),
                            os.path.join(ROOT, "include", "libadsb_iface.hpp")]
 
 
@@ -41,10 +41,10 @@ def build_hip(force=False, verbose=False):
 
 
 def build_synth(force=False):
-    src = os.path.join(CSRC, "synth1090.c")
-    if not force and not _stale(SYNTH, [src, os.path.join(CSRC, "synth1090.h")]):
+    srcs = [os.path.join(CSRC, "synth1090.c"), os.path.join(CSRC, "synth978.c")]
+    if not force and not _stale(SYNTH, srcs + [os.path.join(CSRC, "synth1090.h"), os.path.join(CSRC, "synth978.h")]):
         return SYNTH
-    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-pthread", "-o", SYNTH, src, "-lm"])
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-pthread", "-o", SYNTH] + srcs + ["-lm"])
     return SYNTH
 
 

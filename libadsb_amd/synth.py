@@ -18,14 +18,21 @@ class SynthCfg(C.Structure):
                 ("pct_halfsample", C.c_int32), ("pool_size", C.c_int32)]
 
 
+class Synth978Cfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("noise_amp", C.c_int32), ("amp_lo", C.c_int32), ("amp_hi", C.c_int32),
+                ("mean_gap_bits", C.c_int32), ("pct_uplink", C.c_int32), ("pct_long", C.c_int32), ("pct_corrupt", C.c_int32),
+                ("max_bad_bytes", C.c_int32)]
+
+
+FRAME978_DTYPE = np.dtype([("start", "<u8"), ("kind", "u1"), ("bad_bytes", "u1"), ("len", "<u2"), ("data", "u1", (432,)), ("pad", "u1", (4,))])
+
 FRAME_DTYPE = np.dtype([("start", "<u4"), ("msg", "u1", (14,)), ("nbits", "u1"), ("flipped_bit", "i1"),
                         ("half_sample", "u1"), ("amplitude", "u1")])
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(_SRC):
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-pthread", "-o", _LIB_PATH, _SRC, "-lm"])
-    return _LIB_PATH
+    from . import build as _b
+    return _b.build_synth(force)
 
 
 _lib = None
@@ -42,6 +49,9 @@ def lib():
         L.adsb_synth_fill_range.restype = C.c_long
         L.adsb_synth_pool_addr.argtypes = [C.POINTER(SynthCfg), C.c_uint32]
         L.adsb_synth_pool_addr.restype = C.c_uint32
+        L.adsb_synth978_default.argtypes = [C.POINTER(Synth978Cfg)]
+        L.adsb_synth978_fill.argtypes = [C.POINTER(Synth978Cfg), C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_long]
+        L.adsb_synth978_fill.restype = C.c_long
         _lib = L
     return _lib
 
@@ -73,3 +83,23 @@ def fill_range(first_buf, nbuf, buf_bytes=BUFFER_BYTES, cfg=None, nthreads=None,
     nthreads = nthreads or min(32, os.cpu_count() or 1)
     n = lib().adsb_synth_fill_range(C.byref(cfg), first_buf, nbuf, out.ctypes.data, buf_bytes, nthreads)
     return out, n
+
+
+def default_cfg978(**over):
+    c = Synth978Cfg()
+    lib().adsb_synth978_default(C.byref(c))
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def fill978(stream_index, nbytes, cfg=None, manifest=False):
+    """Synthetic UAT 978 u8 IQ (2 samples per bit).  Returns the array, and the frame manifest when asked."""
+    cfg = cfg or default_cfg978()
+    out = np.empty(nbytes, dtype=np.uint8)
+    if manifest:
+        fr = np.zeros(8192, dtype=FRAME978_DTYPE)
+        n = lib().adsb_synth978_fill(C.byref(cfg), stream_index, out.ctypes.data, nbytes, fr.ctypes.data, fr.size)
+        return out, fr[:min(n, fr.size)]
+    lib().adsb_synth978_fill(C.byref(cfg), stream_index, out.ctypes.data, nbytes, None, 0)
+    return out

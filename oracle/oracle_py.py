@@ -41,7 +41,8 @@ CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Frame), C.POINTER(Aircraft))
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "oracle1090.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("oracle1090.c", "oracle1090.h", "oracle978.c", "oracle978.h")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle1090.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -76,6 +77,17 @@ def lib():
         L.oracle1090_decode_cpr.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.oracle978_phase_lut.argtypes = [C.c_void_p]
+        L.oracle978_create.restype = C.c_void_p
+        L.oracle978_destroy.argtypes = [C.c_void_p]
+        L.oracle978_handle_data.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.oracle978_process_buffer.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.oracle978_rs_parity.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle978_rs_decode.argtypes = [C.c_int, C.c_void_p]
+        L.oracle978_set_carry_full.argtypes = [C.c_void_p, C.c_int]
+        L.oracle978_offset.argtypes = [C.c_void_p]
+        L.oracle978_offset.restype = C.c_uint64
+        L.oracle978_used.argtypes = [C.c_void_p]
+        L.oracle978_used.restype = C.c_size_t
         _lib = L
     return _lib
 
@@ -158,3 +170,69 @@ def gate_offsets(mag):
         out = np.empty(n, dtype=np.uint32)
         n = lib().oracle1090_gate_offsets(mag.ctypes.data, mag.size, out.ctypes.data, n)
     return out[:n].copy()
+
+
+CB978 = C.CFUNCTYPE(None, C.c_void_p, C.c_char, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_uint64)
+
+
+class Oracle978:
+    """UAT978Handler restatement: handle_data returns [(updown, payload bytes, rs_errors, sample_index), ...]."""
+
+    def __init__(self, carry_full=False):
+        self._l = lib()
+        self._h = C.c_void_p(self._l.oracle978_create())
+        if carry_full:
+            self._l.oracle978_set_carry_full(self._h, 1)
+
+    def stream_state(self):
+        return int(self._l.oracle978_offset(self._h)), int(self._l.oracle978_used(self._h))
+
+    def close(self):
+        if self._h:
+            self._l.oracle978_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def handle_data(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        out = []
+
+        def _cb(_u, updown, data, n, rs, idx):
+            out.append((updown.decode(), bytes(data[:n]), int(rs), int(idx)))
+        cb = CB978(_cb)
+        self._l.oracle978_handle_data(self._h, iq.ctypes.data, iq.size, cb, None)
+        return out
+
+
+def process_buffer978(phi, offset=0):
+    """oracle978_process_buffer over a phase array: ([(updown, payload, rs_errors, sample_index)], consumed)."""
+    phi = np.ascontiguousarray(phi, dtype=np.uint16)
+    out = []
+
+    def _cb(_u, updown, data, n, rs, idx):
+        out.append((updown.decode(), bytes(data[:n]), int(rs), int(idx)))
+    cb = CB978(_cb)
+    done = lib().oracle978_process_buffer(phi.ctypes.data, phi.size, offset, cb, None)
+    return out, int(done)
+
+
+def phase_lut978():
+    lut = np.empty(65536, dtype=np.uint16)
+    lib().oracle978_phase_lut(lut.ctypes.data)
+    return lut
+
+
+def rs_parity978(kind, data):
+    nroots = (12, 14, 20)[kind]
+    d = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    par = np.zeros(nroots, dtype=np.uint8)
+    lib().oracle978_rs_parity(kind, d.ctypes.data, par.ctypes.data)
+    return par.tobytes()
+
+
+def rs_decode978(kind, codeword):
+    cw = np.frombuffer(bytes(codeword), dtype=np.uint8).copy()
+    n = lib().oracle978_rs_decode(kind, cw.ctypes.data)
+    return int(n), cw.tobytes()

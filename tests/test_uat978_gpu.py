@@ -1,0 +1,149 @@
+"""UAT 978 on the GPU against oracle/oracle978.c, through the C ABI (parity unpinned: the oracle restates the published
+dump978 legacy algorithm, see its header).  Bit-exact: same frames, same payload bytes, same rs_errors, same stream
+sample index, same consumed counts."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import libadsb_amd as A
+from libadsb_amd import synth
+from oracle import oracle_py as O
+
+import uat_helpers as U
+from test_uat978_cpu import stale_register_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def uat(native_libs):
+    u = A.Uat978()
+    yield u
+    u.close()
+
+
+def test_phase_lut_is_the_reference_table(uat):
+    assert np.array_equal(uat.phase_lut(), O.phase_lut978())
+
+
+@pytest.mark.parametrize("stream,cfg_over", [
+    (0, {}),
+    (1, {"noise_amp": 6, "pct_corrupt": 60, "max_bad_bytes": 8}),     # beyond RS capacity for some frames
+    (2, {"pct_uplink": 50, "mean_gap_bits": 300}),
+    (3, {"amp_lo": 6, "amp_hi": 14, "noise_amp": 4}),                  # weak signals: sync errors, wrong slicing
+    (4, {"mean_gap_bits": 40, "pct_uplink": 0}),                       # back-to-back downlink frames
+])
+@pytest.mark.parametrize("carry_full", [False, True])
+def test_handle_data_matches_oracle(native_libs, stream, cfg_over, carry_full):
+    cfg = synth.default_cfg978(**cfg_over)
+    iq = synth.fill978(stream, 6 * 262144, cfg)
+    u, o = A.Uat978(carry_full=carry_full), O.Oracle978(carry_full=carry_full)
+    total = 0
+    for k in range(6):  # production-sized calls, state carried across them
+        part = iq[k * 262144:(k + 1) * 262144]
+        got, want = u.handle_data(part), o.handle_data(part)
+        assert got == want, (k, len(got), len(want))
+        assert u.stream_state() == o.stream_state()
+        total += len(want)
+    assert total > 20
+    u.close()
+
+
+def test_handle_data_ragged_call_sizes(native_libs):
+    iq = synth.fill978(7, 5 * 262144, synth.default_cfg978())
+    u, o = A.Uat978(), O.Oracle978()
+    rng = np.random.default_rng(7)
+    pos = 0
+    while pos < iq.size:
+        n = int(rng.choice([2, 20000, 65536, 131072, 262144, 300002, 17880]))
+        part = iq[pos:pos + n]
+        assert u.handle_data(part) == o.handle_data(part), pos
+        assert u.stream_state() == o.stream_state()
+        pos += n
+    u.close()
+
+
+def test_process_iq_one_long_buffer(uat):
+    """process_buffer semantics over 8 Mi samples in one call (the batch path) == the oracle on the LUT-mapped phases."""
+    cfg = synth.default_cfg978(pct_corrupt=30, max_bad_bytes=7)
+    iq = synth.fill978(11, 16 * 1024 * 1024, cfg)
+    phi = O.phase_lut978()[iq.view(np.uint16)]
+    want, want_done = O.process_buffer978(phi, offset=12345)
+    got, got_done = uat.process_iq(iq, offset=12345)
+    assert len(want) > 1000
+    assert got == want and got_done == want_done
+
+
+def test_process_phases_and_short_buffers(uat):
+    iq = synth.fill978(12, 2 * 65536, synth.default_cfg978())
+    phi = O.phase_lut978()[iq.view(np.uint16)]
+    for n in (0, 1, 2, 35, 36, 37, 8903, 8904, 8905, 8906, 8940, 9000, 20001, 65536):
+        want = O.process_buffer978(phi[:n])
+        got = uat.process_phases(phi[:n])
+        assert got == want, n
+
+
+def test_noise_only_and_constant_input(uat):
+    rng = np.random.default_rng(3)
+    for iq in (rng.integers(0, 256, 4 * 1024 * 1024, dtype=np.uint8), np.full(1 << 20, 127, dtype=np.uint8),
+               np.zeros(1 << 20, dtype=np.uint8)):
+        phi = O.phase_lut978()[iq.view(np.uint16)]
+        assert uat.process_iq(iq) == O.process_buffer978(phi)
+
+
+def test_stale_register_detection_needs_an_extra_device_lookup(uat):
+    phi, p1, p2 = stale_register_case()
+    before = uat.timing()["extra_lookups"]
+    got = uat.process_phases(phi)
+    assert got == O.process_buffer978(phi)
+    assert [f[1] for f in got[0]] == [p1, p2]
+    assert uat.timing()["extra_lookups"] == before + 1
+
+
+def test_adsb_word_on_one_alignment_hides_uplink_word_on_the_other(uat):
+    """`else if`: when either register holds the ADS-B check word the uplink word is not looked at on that bit.  Built so
+    that the even alignment shows the uplink word and the odd alignment the ADS-B word on the same bit."""
+    rng = np.random.default_rng(9)
+    a = U.bits_of(U.ADSB_SYNC, 36)
+    b = U.bits_of(U.UPLINK_SYNC, 36)
+    # sample-level signs: even samples carry word b, odd samples word a (only the first 18 bits matter for the search)
+    signs = np.empty(72, dtype=np.int64)
+    signs[0::2] = b
+    signs[1::2] = a
+    d = np.concatenate([np.where(np.array(U.quiet_bits(rng, 80)).repeat(2) > 0, U.STEP, -U.STEP),
+                        np.where(signs > 0, U.STEP, -U.STEP),
+                        np.where(np.array(U.quiet_bits(rng, 2 * 4600)).repeat(2) > 0, U.STEP, -U.STEP)])
+    phi = ((1000 + np.concatenate([[0], np.cumsum(d)])) & 0xFFFF).astype(np.uint16)
+    assert uat.process_phases(phi) == O.process_buffer978(phi)
+
+
+def test_reference_seam_process_buffer(native_libs):
+    """init_fec / process_buffer / dump_raw_message: the names UAT978.cpp:9-10 binds."""
+    L = A.lib()
+    frames = []
+
+    def _dump(updown, data, n, rs):
+        frames.append((updown.decode(), bytes(data[:n]), int(rs)))
+    cb = A.DUMP_RAW_MESSAGE(_dump)
+    L.adsb_amd_uat_set_dump_raw_message(cb)
+    try:
+        L.init_fec()
+        iq = synth.fill978(5, 131072, synth.default_cfg978())
+        phi = np.ascontiguousarray(O.phase_lut978()[iq.view(np.uint16)])
+        done = L.process_buffer(phi.ctypes.data, phi.size, 777)
+        want, want_done = O.process_buffer978(phi, 777)
+        assert done == want_done and frames == [f[:3] for f in want] and len(want) > 3
+    finally:
+        L.adsb_amd_uat_set_dump_raw_message(None)
+
+
+def test_device_resident_input(uat):
+    import torch
+    iq = synth.fill978(13, 8 * 1024 * 1024, synth.default_cfg978())
+    d = torch.from_numpy(iq).cuda()
+    torch.cuda.synchronize()
+    got = uat.process_device(d.data_ptr(), iq.size // 2)
+    assert got == O.process_buffer978(O.phase_lut978()[iq.view(np.uint16)])
+    t = uat.timing()
+    assert t["scan_ms"] > 0
