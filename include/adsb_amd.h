@@ -191,7 +191,7 @@ int adsb_amd_uat_set_carry_full(adsb_amd_uat_t* u, int full);
 int adsb_amd_uat_stream_state(const adsb_amd_uat_t* u, uint64_t* offset, size_t* used); /* UAT978Handler::offset / used */
 
 /* process_buffer over one buffer of any length < 2^31 samples (the reference passes <= 65 536): phases from the host, or u8
- * IQ from the host / already in HBM (on_device != 0, 2-byte aligned).  *consumed = samples the caller may drop (negative
+ * IQ from the host / already in HBM (on_device != 0, 16-byte aligned).  *consumed = samples the caller may drop (negative
  * when the buffer is shorter than one maximum frame, as in dump978). */
 int adsb_amd_uat_process_phases(adsb_amd_uat_t* u, const uint16_t* phi_host, uint64_t len, uint64_t offset, adsb_amd_uat_frame_fn cb, void* user,
                                 int64_t* consumed);

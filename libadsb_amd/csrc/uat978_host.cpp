@@ -333,7 +333,7 @@ struct adsb_amd_uat
     int scan(const uint16_t* in_dev, uint64_t n, bool phases_given)
     {
         if (n >= (1ull << 31)) return fail(ADSB_AMD_EINVAL, "UAT stream longer than 2^31 samples per call");
-        int rc = reserve(n, std::max<uint32_t>(cand_cap, 4096), std::max<uint32_t>(uplink_cap, 1024));
+        int rc = reserve(phases_given ? n : 0, std::max<uint32_t>(cand_cap, 4096), std::max<uint32_t>(uplink_cap, 1024)); // sign words: phases path only
         if (rc) return rc;
         nrecords = nuplink = 0;
         by_key.clear();
@@ -349,13 +349,13 @@ struct adsb_amd_uat
             if (ncand > cand_cap)
             { // the match kernel counted past the array: grow and repeat the match
                 if (attempt > 2) return fail(ADSB_AMD_EHIP, "UAT candidate count keeps changing");
-                rc = reserve(n, ncand + ncand / 4 + 64, uplink_cap);
+                rc = reserve(0, ncand + ncand / 4 + 64, uplink_cap);
                 if (rc) return rc;
                 continue;
             }
             if (ncand > uplink_cap)
             {
-                rc = reserve(n, cand_cap, ncand + 64);
+                rc = reserve(0, cand_cap, ncand + 64);
                 if (rc) return rc;
             }
             stat_candidates += ncand;
@@ -409,7 +409,7 @@ struct adsb_amd_uat
         }
         if (nrecords + 1 > cand_cap || nuplink + 1 > uplink_cap)
         { // grow, keeping what is there (rare path; host copies are authoritative, the device arrays only receive)
-            int rc = grow_keep(n);
+            int rc = grow_keep();
             if (rc) return rc;
         }
         const uint32_t raw = (index & 0x7FFFFFFFu) | (kind << 31);
@@ -423,7 +423,7 @@ struct adsb_amd_uat
         return ADSB_AMD_OK;
     }
 
-    int grow_keep(uint64_t n)
+    int grow_keep()
     {
         // new arrays twice the size; device contents are not needed again (records already copied to the host), but the
         // uplink counter keeps counting from nuplink so new records land behind the old ones
@@ -433,7 +433,7 @@ struct adsb_amd_uat
         cand_d = nullptr, adsb_d = nullptr, uplink_d = nullptr;
         const uint32_t nc = cand_cap * 2 + 64, nu = uplink_cap * 2 + 64;
         cand_cap = uplink_cap = 0;
-        int rc = reserve(n, nc, nu);
+        int rc = reserve(0, nc, nu);
         (void)hipFree(oc), (void)hipFree(oa), (void)hipFree(ou);
         return rc;
     }
@@ -705,7 +705,7 @@ extern "C" int adsb_amd_uat_process_iq(adsb_amd_uat_t* u, const void* iq, uint64
         if (rc) return rc;
         dev = reinterpret_cast<const uint16_t*>(u->in_d);
     }
-    else if (reinterpret_cast<uintptr_t>(iq) & 1u) return u->fail(ADSB_AMD_EINVAL, "device IQ pointer must be 2-byte aligned");
+    else if (reinterpret_cast<uintptr_t>(iq) & 15u) return u->fail(ADSB_AMD_EINVAL, "device IQ pointer must be 16-byte aligned");
     return u->process(dev, nsamples, false, offset, cb, user, consumed);
 }
 extern "C" int adsb_amd_uat_timing(const adsb_amd_uat_t* u, float* scan_ms, float* demod_ms, uint64_t* candidates, uint64_t* extra_lookups)
