@@ -202,6 +202,8 @@ int adsb_amd_uat_process_iq(adsb_amd_uat_t* u, const void* iq, uint64_t nsamples
 int adsb_amd_uat_timing(const adsb_amd_uat_t* u, float* scan_ms, float* demod_ms, uint64_t* candidates, uint64_t* extra_lookups);
 int adsb_amd_uat_phase_lut(const adsb_amd_uat_t* u, uint16_t* lut65536);  /* InitATan2Table, UAT978.cpp:76-100 */
 int adsb_amd_uat_rs_decode(int kind, uint8_t* codeword); /* 0 RS(30,18), 1 RS(48,34), 2 RS(92,72); in place; corrected count or -1 */
+/* the same on the GPU, with the decoder the demod kernel uses: `count` packed code words in place, one result each */
+int adsb_amd_uat_rs_decode_device(adsb_amd_uat_t* u, int kind, uint8_t* codewords, int count, int* results);
 
 /* The reference's own seam, for a host that links this library instead of dump978's legacy objects.  init_fec() creates a
  * process-wide context on device $ADSB_AMD_DEVICE (default 0) and aborts with a message when there is no usable GPU;

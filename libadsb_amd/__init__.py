@@ -33,7 +33,7 @@ EXPORTS = [
     "adsb_amd_handler_set_sample_clock", "adsb_amd_handler_handle_data",
     "adsb_amd_uat_create", "adsb_amd_uat_destroy", "adsb_amd_uat_last_error", "adsb_amd_uat_handle_data", "adsb_amd_uat_set_carry_full",
     "adsb_amd_uat_stream_state", "adsb_amd_uat_process_phases", "adsb_amd_uat_process_iq", "adsb_amd_uat_timing", "adsb_amd_uat_phase_lut",
-    "adsb_amd_uat_rs_decode", "adsb_amd_uat_set_dump_raw_message", "init_fec", "process_buffer",
+    "adsb_amd_uat_rs_decode", "adsb_amd_uat_rs_decode_device", "adsb_amd_uat_set_dump_raw_message", "init_fec", "process_buffer",
 ]
 
 
@@ -94,6 +94,7 @@ def lib():
         L.adsb_amd_uat_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.adsb_amd_uat_phase_lut.argtypes = [C.c_void_p, C.c_void_p]
         L.adsb_amd_uat_rs_decode.argtypes = [C.c_int, C.c_void_p]
+        L.adsb_amd_uat_rs_decode_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.adsb_amd_uat_set_dump_raw_message.argtypes = [C.c_void_p]
         L.init_fec.restype = None
         L.process_buffer.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
@@ -319,6 +320,13 @@ class Uat978:
         a, b, c, d = C.c_float(), C.c_float(), C.c_uint64(), C.c_uint64()
         self._l.adsb_amd_uat_timing(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
         return {"scan_ms": a.value, "demod_ms": b.value, "candidates": c.value, "extra_lookups": d.value}
+
+    def rs_decode_device(self, kind, words):
+        """words: (count, 30 | 48 | 92) uint8 -> (results int32[count], corrected words)."""
+        w = np.ascontiguousarray(words, dtype=np.uint8).copy()
+        res = np.empty(w.shape[0], dtype=np.int32)
+        self._check(self._l.adsb_amd_uat_rs_decode_device(self._h, kind, w.ctypes.data, w.shape[0], res.ctypes.data))
+        return res, w
 
     def phase_lut(self):
         lut = np.empty(65536, dtype=np.uint16)

@@ -13,41 +13,41 @@ constexpr int kUatUplinkBytes = 552;
 constexpr int kUatUplinkBits  = kUatUplinkBytes * 8;
 
 // one per 18-bit match, in candidate order; variant v = frame taken from sample index + v
-struct uat_adsb_rec_t
+struct uat_rec_t
 {
-    uint32_t index;       // sample index of the first sync bit
-    uint32_t uplink_slot; // kind 1: where the uplink record went
-    uint8_t  kind;        // 0 = ADS-B sync word, 1 = uplink sync word
-    uint8_t  ok[2];       // 36-bit sync re-check passed
-    uint8_t  pad;
-    int16_t  center[2];
-    uint8_t  frame[2][kUatLongBytes];
-    uint64_t window;   // sign bits of samples [2 * (index >> 1), +64): both 18-bit registers at detection time
-    uint64_t after[2]; // sign bits of the 64 samples from bit (index >> 1) + 276 + 1 (short) / + 420 + 1 (long; uplink: + 4452 + 1 in [0])
+    uint32_t index;      // sample index of the first sync bit
+    uint8_t  kind;       // 0 = ADS-B sync word, 1 = uplink sync word
+    uint8_t  sync_ok[2]; // 36-bit sync re-check passed
+    uint8_t  pad0;
+    int16_t  skip[2];    // bits the scan loop jumps when it takes this variant: 276 short, 420 long, 4452 uplink; 0 = no frame
+    int16_t  rs[2];      // corrected symbols (uplink: sum over the six blocks); 9999 = no frame
+    uint32_t slot[2];    // uplink: 432-byte slot of the decoded payload in the side array
+    uint32_t pad1;
+    uint64_t window;     // sign bits of samples [2 * (index >> 1), +64): both 18-bit registers at detection time
+    uint64_t after[2];   // sign bits of the 64 samples from bit (index >> 1) + skip + 1 on: [0] short / uplink, [1] long
+    uint8_t  payload[2][34 + 2]; // ADS-B: corrected frame bytes 0..33 (18 of them for a short frame)
 };
-struct uat_uplink_rec_t
-{
-    uint8_t ok[2];
-    uint8_t pad[2];
-    int16_t center[2];
-    uint8_t frame[2][kUatUplinkBytes];
-};
+static_assert(sizeof(uat_rec_t) == 128, "record layout");
+
+struct RsTables;
 
 struct UatArgs
 {
-    const uint16_t*   in;  // u8 IQ pairs as u16 (phases_given == 0) or u16 phases (phases_given == 1)
-    const uint16_t*   lut; // 65536-entry phase LUT
-    uint64_t          nsamples;
-    int               phases_given;
-    uint64_t*         signs; // ceil(nsamples / 64) + 2 words
-    uint32_t*         cand;
-    uint32_t          cand_cap;
-    uint32_t*         counts; // [0] candidates, [1] uplink records
-    uat_adsb_rec_t*   adsb;   // cand_cap entries
-    uat_uplink_rec_t* uplink;
-    uint32_t          uplink_cap;
+    const uint16_t* in;  // u8 IQ pairs as u16 (phases_given == 0) or u16 phases (phases_given == 1)
+    const uint16_t* lut; // 65536-entry phase LUT
+    const RsTables* rs_tables;
+    uint64_t        nsamples;
+    int             phases_given;
+    uint64_t*       signs; // phases path only: ceil(nsamples / 64) + 2 words
+    uint32_t*       cand;
+    uint32_t        cand_cap;
+    uint32_t*       counts; // [0] candidates, [1] uplink payload slots
+    uat_rec_t*      recs;   // cand_cap entries
+    uint8_t*        uplink_payloads; // uplink_cap x 432 bytes
+    uint32_t        uplink_cap;
 };
 
 hipError_t launch_uat978(const UatArgs& a, hipStream_t stream);                       // signs + 18-bit match
 hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, hipStream_t stream); // one wave per candidate
+hipError_t launch_uat978_rs_selftest(const RsTables* tables, int kind, uint8_t* words, int* results, int count, hipStream_t stream);
 } // namespace adsb_amd

@@ -16,6 +16,7 @@
 
 #include <stdint.h>
 
+#include "rs978.h"
 #include "uat978.h"
 
 namespace adsb_amd
@@ -298,15 +299,13 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
     }
 }
 
-// ---- K3: one wave per candidate
+// ---- K3: one wave per candidate: sync re-check, slicing, Reed-Solomon, for the candidate sample and the next one
 struct SyncCheck
 {
     bool ok;
     int  center;
 };
 
-// check_sync_word: centre = mean of the per-class means of dphi over the 36 sync bits (C integer division), then at most
-// four bits on the wrong side of it
 template <bool PHASES_GIVEN>
 __device__ __forceinline__ int dphi_at(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n, uint64_t s)
 {
@@ -323,6 +322,8 @@ __device__ __forceinline__ uint64_t sign_window(const uint16_t* __restrict__ in,
     return __ballot(dphi_at<PHASES_GIVEN>(in, lut, n, p + (uint64_t)lane) > 0);
 }
 
+// check_sync_word: centre = mean of the per-class means of dphi over the 36 sync bits (C integer division), then at most
+// four bits on the wrong side of it
 template <bool PHASES_GIVEN>
 __device__ __forceinline__ SyncCheck check_sync(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n, uint64_t start,
                                                 uint64_t pattern, int lane)
@@ -340,94 +341,322 @@ __device__ __forceinline__ SyncCheck check_sync(const uint16_t* __restrict__ in,
     return r;
 }
 
-// slice `nbits` frame bits starting at sample `start` (first bit after the sync word), MSB-first bytes into out[]
+// slice `nbits` frame bits starting at sample `start` (first bit after the sync word), MSB-first bytes into out[] (LDS).
+// Eight groups of 64 bits per trip so that their (dependent: sample, then LUT) loads are in flight together.
 template <bool PHASES_GIVEN>
 __device__ __forceinline__ void slice_frame(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n, uint64_t start,
-                                            int center, int nbits, uint8_t* __restrict__ out, int lane)
+                                            int center, int nbits, uint8_t* out, int lane)
 {
-    for (int base = 0; base < nbits; base += 64)
+    constexpr int kGroups = 8;
+    for (int base = 0; base < nbits; base += 64 * kGroups)
     {
-        const int      b    = base + lane;
-        const int      d    = (b < nbits) ? dphi_at<PHASES_GIVEN>(in, lut, n, start + 2ull * (uint64_t)b) : 0;
-        const uint64_t bits = __ballot(b < nbits && d > center); // bit `lane` = frame bit base + lane
-        if (lane < 8 && base + 8 * lane < nbits)
-        { // byte k of this group = frame bits base + 8k .. 8k + 7, first bit = MSB
-            const uint32_t byte = (uint32_t)(bits >> (8 * lane)) & 0xFFu;
-            out[(base >> 3) + lane] = (uint8_t)(__builtin_bitreverse32(byte) >> 24);
+        uint32_t a[kGroups], b[kGroups];
+#pragma unroll
+        for (int u = 0; u < kGroups; u++)
+        {
+            const int      bit = base + u * 64 + lane;
+            const uint64_t s   = start + 2ull * (uint64_t)bit;
+            const bool     in_range = bit < nbits && s + 1 < n;
+            a[u] = in[in_range ? s : 0], b[u] = in[in_range ? s + 1 : 0];
         }
+        if (!PHASES_GIVEN)
+        {
+#pragma unroll
+            for (int u = 0; u < kGroups; u++) a[u] = lut[a[u]], b[u] = lut[b[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < kGroups; u++)
+        {
+            const int      gbase = base + u * 64, bit = gbase + lane;
+            const uint64_t s     = start + 2ull * (uint64_t)bit;
+            const int      d     = (bit < nbits && s + 1 < n) ? phi_difference(a[u], b[u]) : 0;
+            const uint64_t bits  = __ballot(bit < nbits && d > center); // bit `lane` = frame bit gbase + lane
+            if (lane < 8 && gbase + 8 * lane < nbits)
+            { // byte k of this group = frame bits gbase + 8k .. 8k + 7, first bit = MSB
+                const uint32_t byte      = (uint32_t)(bits >> (8 * lane)) & 0xFFu;
+                out[(gbase >> 3) + lane] = (uint8_t)(__builtin_bitreverse32(byte) >> 24);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"), __builtin_amdgcn_wave_barrier(), __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
+// ---- Reed-Solomon with the whole wave on one code word.  Same procedure and same results as rs978_decode_with_syndromes
+// (rs978.h; the host build of that one is what the CPU tests hold against the oracle, and tests/test_uat978_gpu.py holds
+// this one against it on random words), laid out across lanes: lane i owns coefficient i of lambda and b during
+// Berlekamp-Massey, the Chien search tries four field elements per lane, Forney runs one lane per root.
+// w.s[0 .. nr) holds the syndromes.  Every lane must call; the result is the same in every lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or_zero_x(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ int wave_xor_i(int x)
+{
+    x ^= dpp_or_zero_x<0x111, 0xF>(x);
+    x ^= dpp_or_zero_x<0x112, 0xF>(x);
+    x ^= dpp_or_zero_x<0x114, 0xF>(x);
+    x ^= dpp_or_zero_x<0x118, 0xF>(x);
+    x ^= dpp_or_zero_x<0x142, 0xA>(x);
+    x ^= dpp_or_zero_x<0x143, 0xC>(x);
+    return __builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ int      gf_fold(int x) { return (x & 255) + (x >> 8); } // == x mod 255 as an index into exp[] (< 510 for x < 65536)
+__device__ __forceinline__ uint32_t gf_mul(const RsTables& T, uint32_t a, uint32_t b) { return (a && b) ? T.exp[T.log[a] + T.log[b]] : 0u; }
+
+__device__ int rs_decode_wave(const RsTables& T, int nr, int pad, uint8_t* data, int stride, RsWork& w, int lane)
+{
+    const uint32_t syn = lane < nr ? w.s[lane] : 0u;
+    if (__ballot(syn != 0) == 0) return 0;
+
+    // Berlekamp-Massey: lane i holds lambda[i] and b[i]
+    uint32_t lam = lane == 0, bb = lane == 0;
+    int      el  = 0;
+    for (int r = 1; r <= nr; r++)
+    {
+        const uint32_t sv      = lane < r ? w.s[r - 1 - lane] : 0u;
+        const uint32_t discr   = (uint32_t)wave_xor_i((int)gf_mul(T, lam, sv));
+        const uint32_t b_shift = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bb, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+        if (discr == 0) bb = b_shift;
+        else
+        {
+            const uint32_t t = lam ^ gf_mul(T, discr, b_shift);
+            if (2 * el <= r - 1)
+            {
+                el = r - el;
+                bb = lam ? T.exp[T.log[lam] + 255 - T.log[discr]] : 0u;
+            }
+            else bb = b_shift;
+            lam = t;
+        }
+        if (lane > nr) lam = 0, bb = 0;
+    }
+    const uint64_t nz  = __ballot(lam != 0);
+    const int      deg = nz ? 63 - __builtin_clzll(nz) : 0;
+    if (lane <= nr) w.lambda[lane] = (uint8_t)lam;
+    wave_fence();
+
+    // Chien search: X^-1 = alpha^i for i = 1 .. 255, four per lane
+    int count = 0;
+#pragma unroll 1
+    for (int k = 0; k < 4; k++)
+    {
+        const int i = 1 + lane + 64 * k;
+        uint32_t  q = 1;
+        for (int j = 1; j <= deg; j++)
+        {
+            const uint32_t lj = w.lambda[j];
+            if (lj) q ^= T.exp[gf_fold(T.log[lj] + j * i)];
+        }
+        const bool     hit  = i <= 255 && q == 0;
+        const uint64_t hits = __ballot(hit);
+        if (hit)
+        {
+            const int at = count + __builtin_popcountll(hits & ((1ull << lane) - 1ull));
+            if (at < kRsMaxRoots) w.root[at] = (uint8_t)i, w.loc[at] = (uint8_t)(i - 1);
+        }
+        count += __builtin_popcountll(hits);
+    }
+    if (count != deg) return -1;
+
+    // omega(x) = s(x) lambda(x) mod x^deg, one coefficient per lane
+    if (lane < deg)
+    {
+        uint32_t acc = 0;
+        for (int j = 0; j <= lane; j++) acc ^= gf_mul(T, w.s[lane - j], w.lambda[j]);
+        w.omega[lane] = (uint8_t)acc;
+    }
+    wave_fence();
+    // Forney, one root per lane
+    if (lane < count)
+    {
+        const int rt   = w.root[lane];
+        uint32_t  num1 = 0, den = 0;
+        for (int i = deg - 1; i >= 0; i--)
+            if (w.omega[i]) num1 ^= T.exp[gf_fold(T.log[w.omega[i]] + i * rt)];
+        const uint32_t num2 = T.exp[gf_fold(rt * (kRsFcr - 1) + 255)];
+        const int      top  = (deg < nr - 1 ? deg : nr - 1) & ~1;
+        for (int i = top; i >= 0; i -= 2)
+            if (w.lambda[i + 1]) den ^= T.exp[gf_fold(T.log[w.lambda[i + 1]] + i * rt)];
+        if (num1 != 0 && (int)w.loc[lane] >= pad)
+        {
+            const int lden = den ? T.log[den] : 255;
+            data[((int)w.loc[lane] - pad) * stride] ^= T.exp[gf_fold(T.log[num1] + T.log[num2] + 255 - lden)];
+        }
+    }
+    wave_fence();
+    return count;
+}
+
+// correct_adsb_frame with the wave on one slicing: w.s = the 14 long syndromes, short_syn = the 12 short ones of the
+// untouched frame.  Returns the bits to jump (0 = neither); *rs = corrected symbols (9999 = neither).  Uniform.
+__device__ int correct_adsb_wave(const RsTables& T, uint8_t* frame48, RsWork& w, const uint8_t* short_syn, int lane, int* rs)
+{
+    int n = rs_decode_wave(T, 14, 207, frame48, 1, w, lane);
+    if (n >= 0 && n <= 7 && (frame48[0] >> 3) != 0)
+    {
+        *rs = n;
+        return kUatLongSkip;
+    }
+    if (lane < 12) w.s[lane] = n > 0 ? rs978_syndrome(T, lane, 30, frame48, 1) : short_syn[lane]; // the long attempt changed the frame iff n > 0
+    wave_fence();
+    n = rs_decode_wave(T, 12, 225, frame48, 1, w, lane);
+    if (n >= 0 && n <= 6 && (frame48[0] >> 3) == 0)
+    {
+        *rs = n;
+        return kUatShortSkip;
+    }
+    *rs = 9999;
+    return 0;
+}
+
+// test hook: decode `count` independent code words of one code, one wave each (kind 0/1/2 as in adsb_amd_uat_rs_decode)
+__global__ __launch_bounds__(64) void uat_rs_selftest_kernel(const RsTables* __restrict__ rs_tables, int kind, uint8_t* words, int* results, int count)
+{
+    __shared__ RsTables T;
+    __shared__ RsWork   w;
+    __shared__ uint8_t  cw[96];
+    const int lane = threadIdx.x;
+    const int nr = kind == 0 ? 12 : kind == 1 ? 14 : 20, pad = kind == 0 ? 225 : kind == 1 ? 207 : 163, n = 255 - pad;
+    for (int i = lane; i < (int)sizeof(RsTables) / 4; i += 64) reinterpret_cast<uint32_t*>(&T)[i] = reinterpret_cast<const uint32_t*>(rs_tables)[i];
+    wave_fence();
+    for (int c = blockIdx.x; c < count; c += gridDim.x)
+    {
+        for (int i = lane; i < n; i += 64) cw[i] = words[(size_t)c * n + i];
+        wave_fence();
+        if (lane < nr) w.s[lane] = rs978_syndrome(T, lane, n, cw, 1);
+        wave_fence();
+        const int r = rs_decode_wave(T, nr, pad, cw, 1, w, lane);
+        for (int i = lane; i < n; i += 64) words[(size_t)c * n + i] = cw[i];
+        if (lane == 0) results[c] = r;
+        wave_fence();
     }
 }
 
 template <bool PHASES_GIVEN>
 __global__ __launch_bounds__(64) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
-                                                       const uint32_t* __restrict__ cand, uint32_t ncand, uat_adsb_rec_t* __restrict__ adsb,
-                                                       uat_uplink_rec_t* __restrict__ uplink, uint32_t uplink_cap,
+                                                       const RsTables* __restrict__ rs_tables, const uint32_t* __restrict__ cand, uint32_t ncand,
+                                                       uat_rec_t* __restrict__ recs, uint8_t* __restrict__ uplink_payloads, uint32_t uplink_cap,
                                                        uint32_t* __restrict__ uplink_count)
 {
+    __shared__ RsTables T;
+    __shared__ uint8_t  raw[2][kUatUplinkBytes + 8];
+    __shared__ RsWork   work[12];
+    __shared__ uint8_t  short_syn[2][12];
     const int lane = threadIdx.x;
+    for (int i = lane; i < (int)sizeof(RsTables) / 4; i += 64) reinterpret_cast<uint32_t*>(&T)[i] = reinterpret_cast<const uint32_t*>(rs_tables)[i];
+    wave_fence();
+
     for (uint32_t c = blockIdx.x; c < ncand; c += gridDim.x)
     {
-        const uint32_t raw  = cand[c];
-        const uint32_t kind = raw >> 31;
-        const uint64_t idx  = raw & 0x7FFFFFFFu;
+        const uint32_t word = cand[c];
+        const uint32_t kind = word >> 31;
+        const uint64_t idx  = word & 0x7FFFFFFFu;
+        const uint64_t sb   = idx >> 1;
+        uat_rec_t*     r    = &recs[c];
+        const uint64_t w0   = sign_window<PHASES_GIVEN>(in, lut, n, 2 * sb, lane);
+        const uint64_t w1   = sign_window<PHASES_GIVEN>(in, lut, n, 2 * (sb + (kind ? kUatUplinkSkip : kUatShortSkip) + 1), lane);
+        const uint64_t w2   = kind ? 0 : sign_window<PHASES_GIVEN>(in, lut, n, 2 * (sb + kUatLongSkip + 1), lane);
+        const int      nbits = kind ? kUatUplinkBits : kUatLongBytes * 8;
+        bool           ok[2];
+#pragma unroll 1
+        for (int v = 0; v < 2; v++)
+        {
+            const SyncCheck sc = check_sync<PHASES_GIVEN>(in, lut, n, idx + (uint64_t)v, kind ? kUplinkSync : kAdsbSync, lane);
+            ok[v]              = sc.ok;
+            if (sc.ok) slice_frame<PHASES_GIVEN>(in, lut, n, idx + (uint64_t)v + 72, sc.center, nbits, raw[v], lane);
+        }
+        wave_fence();
+        // Reed-Solomon.  Syndromes first, one per lane (each is a Horner pass over the whole code word); then one lane per
+        // code word for the rest, which ends at once when its syndromes are all zero (2 lanes for ADS-B: one per slicing;
+        // 12 for an uplink frame: 2 x 6 interleaved blocks)
+        int skip = 0, rs = 9999; // valid in lane v (ADS-B) / lane 6 v (uplink) afterwards
         if (kind == 0)
         {
-            uat_adsb_rec_t* r = &adsb[c];
-            const uint64_t sb = idx >> 1;
-            const uint64_t w0 = sign_window<PHASES_GIVEN>(in, lut, n, 2 * sb, lane);
-            const uint64_t w1 = sign_window<PHASES_GIVEN>(in, lut, n, 2 * (sb + 36 + 240 + 1), lane);
-            const uint64_t w2 = sign_window<PHASES_GIVEN>(in, lut, n, 2 * (sb + 36 + 384 + 1), lane);
-            if (lane == 0)
-            {
-                r->index    = (uint32_t)idx;
-                r->kind     = 0;
-                r->window   = w0;
-                r->after[0] = w1;
-                r->after[1] = w2;
-            }
-#pragma unroll
-            for (int v = 0; v < 2; v++)
-            {
-                const SyncCheck sc = check_sync<PHASES_GIVEN>(in, lut, n, idx + (uint64_t)v, kAdsbSync, lane);
-                if (lane == 0)
+            { // lanes 0..27: the 14 long syndromes of slicing lane / 14; lanes 32..55: the 12 short ones of slicing (lane - 32) / 12
+                const bool is_long = lane < 28, is_short = lane >= 32 && lane < 56;
+                const int  v = is_long ? lane / 14 : (lane - 32) / 12, i = is_long ? lane % 14 : (lane - 32) % 12;
+                if ((is_long || is_short) && ok[v & 1])
                 {
-                    r->ok[v]     = sc.ok ? 1 : 0;
-                    r->center[v] = (int16_t)sc.center;
+                    const uint8_t syn = rs978_syndrome(T, i, is_long ? 48 : 30, raw[v], 1);
+                    if (is_long) work[v].s[i] = syn;
+                    else short_syn[v][i] = syn;
                 }
-                if (sc.ok) slice_frame<PHASES_GIVEN>(in, lut, n, idx + (uint64_t)v + 72, sc.center, 384, r->frame[v], lane);
+            }
+            wave_fence();
+#pragma unroll 1
+            for (int v = 0; v < 2; v++)
+                if (ok[v])
+                {
+                    int       rs_v   = 9999;
+                    const int skip_v = correct_adsb_wave(T, raw[v], work[v], short_syn[v], lane, &rs_v);
+                    if (lane == v) skip = skip_v, rs = rs_v;
+                }
+        }
+        else
+        {
+            for (int k = lane; k < 12 * 20; k += 64)
+            {
+                const int cw = k / 20, i = k % 20;
+                if (ok[cw / 6]) work[cw].s[i] = rs978_syndrome(T, i, 92, raw[cw / 6] + cw % 6, 6);
+            }
+            wave_fence();
+#pragma unroll 1
+            for (int v = 0; v < 2; v++)
+                if (ok[v])
+                { // correct_uplink_frame: every block within 10 corrections
+                    int  total = 0;
+                    bool good  = true;
+#pragma unroll 1
+                    for (int blk = 0; blk < 6 && good; blk++)
+                    {
+                        const int nb = rs_decode_wave(T, 20, 163, raw[v] + blk, 6, work[v * 6 + blk], lane);
+                        good         = nb >= 0 && nb <= 10;
+                        total += nb;
+                    }
+                    if (good && lane == 6 * v) skip = kUatUplinkSkip, rs = total;
+                }
+        }
+        wave_fence();
+        const int src0 = 0, src1 = kind ? 6 : 1;
+        const int skip0 = __builtin_amdgcn_readlane(skip, src0), skip1 = __builtin_amdgcn_readlane(skip, src1);
+        const int rs0 = __builtin_amdgcn_readlane(rs, src0), rs1 = __builtin_amdgcn_readlane(rs, src1);
+        uint32_t slot[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (kind)
+        { // decoded uplink payloads go to a side array, one 432-byte slot each
+            const int want = (skip0 ? 1 : 0) + (skip1 ? 1 : 0);
+            if (want)
+            {
+                uint32_t first = 0;
+                if (lane == 0) first = atomicAdd(uplink_count, (uint32_t)want);
+                first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+                if (skip0) slot[0] = first;
+                if (skip1) slot[1] = first + (skip0 ? 1u : 0u);
+#pragma unroll 1
+                for (int v = 0; v < 2; v++)
+                    if (slot[v] < uplink_cap)
+                        for (int k = lane; k < 432; k += 64) uplink_payloads[(size_t)slot[v] * 432 + k] = raw[v][(k % 72) * 6 + k / 72];
             }
         }
         else
         {
-            const uint64_t sb = idx >> 1;
-            const uint64_t w0 = sign_window<PHASES_GIVEN>(in, lut, n, 2 * sb, lane);
-            const uint64_t w1 = sign_window<PHASES_GIVEN>(in, lut, n, 2 * (sb + 36 + 4416 + 1), lane);
-            if (lane == 0)
+            if (lane < 34)
             {
-                adsb[c].index    = (uint32_t)idx;
-                adsb[c].kind     = 1;
-                adsb[c].window   = w0;
-                adsb[c].after[0] = w1;
-                adsb[c].after[1] = 0;
-            }
-            uint32_t slot = 0;
-            if (lane == 0) slot = atomicAdd(uplink_count, 1u);
-            slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-            if (lane == 0) adsb[c].uplink_slot = slot;
-            if (slot >= uplink_cap) continue;
-            uat_uplink_rec_t* r = &uplink[slot];
-#pragma unroll 1
-            for (int v = 0; v < 2; v++)
-            {
-                const SyncCheck sc = check_sync<PHASES_GIVEN>(in, lut, n, idx + (uint64_t)v, kUplinkSync, lane);
-                if (lane == 0)
-                {
-                    r->ok[v]     = sc.ok ? 1 : 0;
-                    r->center[v] = (int16_t)sc.center;
-                }
-                if (sc.ok) slice_frame<PHASES_GIVEN>(in, lut, n, idx + (uint64_t)v + 72, sc.center, 4416, r->frame[v], lane);
+                if (skip0) r->payload[0][lane] = raw[0][lane];
+                if (skip1) r->payload[1][lane] = raw[1][lane];
             }
         }
+        if (lane == 0)
+        {
+            r->index = (uint32_t)idx, r->kind = (uint8_t)kind;
+            r->sync_ok[0] = ok[0], r->sync_ok[1] = ok[1];
+            r->skip[0] = (int16_t)skip0, r->skip[1] = (int16_t)skip1;
+            r->rs[0] = (int16_t)rs0, r->rs[1] = (int16_t)rs1;
+            r->slot[0] = slot[0], r->slot[1] = slot[1];
+            r->window = w0, r->after[0] = w1, r->after[1] = w2;
+        }
+        wave_fence(); // raw[] is reused by the next candidate
     }
 }
 } // namespace
@@ -461,13 +690,20 @@ hipError_t launch_uat978(const UatArgs& a, hipStream_t stream)
 hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, hipStream_t stream)
 {
     if (ncand == 0) return hipSuccess;
-    uint32_t g = ncand > 4096 ? 4096 : ncand;
+    uint32_t g = ncand > 8192 ? 8192 : ncand;
     if (a.phases_given)
-        hipLaunchKernelGGL(uat_demod_kernel<true>, dim3(g), dim3(64), 0, stream, a.in, a.lut, a.nsamples, a.cand, ncand, a.adsb, a.uplink, a.uplink_cap,
-                           a.counts + 1);
+        hipLaunchKernelGGL(uat_demod_kernel<true>, dim3(g), dim3(64), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
+                           a.uplink_payloads, a.uplink_cap, a.counts + 1);
     else
-        hipLaunchKernelGGL(uat_demod_kernel<false>, dim3(g), dim3(64), 0, stream, a.in, a.lut, a.nsamples, a.cand, ncand, a.adsb, a.uplink, a.uplink_cap,
-                           a.counts + 1);
+        hipLaunchKernelGGL(uat_demod_kernel<false>, dim3(g), dim3(64), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
+                           a.uplink_payloads, a.uplink_cap, a.counts + 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_uat978_rs_selftest(const RsTables* tables, int kind, uint8_t* words, int* results, int count, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(uat_rs_selftest_kernel, dim3(count > 4096 ? 4096 : count), dim3(64), 0, stream, tables, kind, words, results, count);
     return hipGetLastError();
 }
 

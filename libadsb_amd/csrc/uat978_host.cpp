@@ -1,14 +1,16 @@
 // uat978_host.cpp -- host half of the UAT 978 path and its C ABI (include/adsb_amd.h, "UAT 978" section).
 //
-//   GPU (uat978.hip)   sign of the phase difference for every sample, every exact 18-bit sync match, and for each match
-//                      the 36-bit sync re-check + sliced frame for the match and for the next sample
-//   host (this file)   what the dump978 scan loop does with those: which match the loop reaches (it jumps over a decoded
-//                      frame and does not clear its two shift registers when it does), Reed-Solomon, choice between the
-//                      two slicings, up-call.  Plus UAT978Handler::HandleData's staging/re-buffering (UAT978.cpp:43-60).
+//   GPU (uat978.hip)   phases, sign of the phase difference for every sample, every exact 18-bit sync match, and for each
+//                      match: the 36-bit sync re-check, the sliced frame and its Reed-Solomon decode, for the match and
+//                      for the next sample
+//   host (this file)   what the dump978 scan loop does with those, in stream order: which match the loop reaches (it jumps
+//                      over a decoded frame and does not clear its two shift registers when it does), the choice between
+//                      the two slicings, the up-call.  Plus UAT978Handler::HandleData's staging/re-buffering
+//                      (UAT978.cpp:43-60).
 //
 // The algorithm restated here is the published dump978 legacy demodulator; it is un-vendored in the reference tree
 // (SURVEY.md F7), so parity is unpinned: tests compare this path with oracle/oracle978.c on generated streams.
-// There is no CPU demodulator in this file: phases, signs, matches and slicing only ever come from the device.
+// There is no CPU demodulator in this file: phases, signs, matches, slicing and FEC only ever come from the device.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -23,6 +25,7 @@
 #include <vector>
 
 #include "adsb_amd.h"
+#include "rs978.h"
 #include "scan1090.h"
 #include "uat978.h"
 
@@ -30,177 +33,19 @@ using namespace adsb_amd;
 
 namespace
 {
-// ------------------------------------------------------------------------------------------------------------------
-// Reed-Solomon over GF(256), field polynomial 0x187, first consecutive root 120, primitive element 1: the three codes
-// init_fec() sets up (RS(30,18), RS(48,34), RS(92,72) as shortened RS(255, 255 - nroots)).  The decoder follows the
-// classic Berlekamp-Massey / Chien / Forney procedure with libfec's conventions, because results on words that are
-// NOT within the correction radius (or whose "errors" fall into the zero padding) depend on the procedure:
-// corrections located in the padding are dropped but still counted, and a zero Forney denominator is not rejected.
-// ------------------------------------------------------------------------------------------------------------------
-class ReedSolomon
+const RsTables& rs_tables()
 {
-  public:
-    ReedSolomon(int nroots, int pad) : nroots_(nroots), pad_(pad)
+    static const RsTables t = []
     {
-        int x = 1;
-        for (int i = 0; i < 255; i++)
-        {
-            exp_[i] = exp_[i + 255] = (uint8_t)x;
-            log_[x]                 = i;
-            x <<= 1;
-            if (x & 0x100) x ^= 0x187;
-        }
-        log_[0] = -1;
-    }
-    int codeword_bytes() const { return 255 - pad_; }
-
-    // in place; returns the number of located errors or -1 (data untouched)
-    int decode(uint8_t* data) const
-    {
-        const int nr = nroots_, n = 255 - pad_;
-        uint8_t   s[32];
-        bool      any = false;
-        for (int i = 0; i < nr; i++)
-        {
-            uint8_t   acc = 0;
-            const int a   = (kFcr + i) % 255;
-            for (int j = 0; j < n; j++) acc = (uint8_t)(mul_exp(acc, a) ^ data[j]);
-            s[i] = acc;
-            any |= acc != 0;
-        }
-        if (!any) return 0;
-
-        uint8_t lambda[33] = {1}, b[33] = {1}, t[33];
-        int     el = 0;
-        for (int r = 1; r <= nr; r++)
-        {
-            uint8_t discr = 0;
-            for (int i = 0; i < r; i++) discr ^= mul(lambda[i], s[r - i - 1]);
-            if (discr == 0)
-            {
-                std::memmove(b + 1, b, (size_t)nr);
-                b[0] = 0;
-                continue;
-            }
-            t[0] = lambda[0];
-            for (int i = 0; i < nr; i++) t[i + 1] = (uint8_t)(lambda[i + 1] ^ mul(discr, b[i]));
-            if (2 * el <= r - 1)
-            {
-                el = r - el;
-                for (int i = 0; i <= nr; i++) b[i] = div(lambda[i], discr);
-            }
-            else
-            {
-                std::memmove(b + 1, b, (size_t)nr);
-                b[0] = 0;
-            }
-            std::memcpy(lambda, t, (size_t)nr + 1);
-        }
-        int deg = 0;
-        for (int i = 0; i <= nr; i++)
-            if (lambda[i]) deg = i;
-
-        // roots of lambda: X^-1 = alpha^i  <=>  error at position (i - 1) counted from the end of the full 255 word
-        int root[32], loc[32], count = 0;
-        for (int i = 1; i <= 255 && count < deg; i++)
-        {
-            uint8_t q = 1;
-            for (int j = 1; j <= deg; j++)
-                if (lambda[j]) q ^= exp_[(log_[lambda[j]] + j * i) % 255];
-            if (q) continue;
-            root[count] = i;
-            loc[count]  = i - 1;
-            count++;
-        }
-        if (count != deg) return -1;
-
-        uint8_t omega[33];
-        for (int i = 0; i < deg; i++)
-        {
-            uint8_t acc = 0;
-            for (int j = 0; j <= i; j++) acc ^= mul(s[i - j], lambda[j]);
-            omega[i] = acc;
-        }
-        for (int j = count - 1; j >= 0; j--)
-        {
-            uint8_t num1 = 0;
-            for (int i = deg - 1; i >= 0; i--)
-                if (omega[i]) num1 ^= exp_[(log_[omega[i]] + i * root[j]) % 255];
-            const uint8_t num2 = exp_[(root[j] * (kFcr - 1) + 255) % 255];
-            uint8_t       den  = 0;
-            for (int i = std::min(deg, nr - 1) & ~1; i >= 0; i -= 2)
-                if (lambda[i + 1]) den ^= exp_[(log_[lambda[i + 1]] + i * root[j]) % 255];
-            if (num1 != 0 && loc[j] >= pad_)
-            {
-                const int lden = den ? log_[den] : 255; // index form of zero is 255 in libfec: the exponent then gains 255 - 255
-                data[loc[j] - pad_] ^= exp_[(log_[num1] + log_[num2] + 255 - lden) % 255];
-            }
-        }
-        return count;
-    }
-
-  private:
-    static constexpr int kFcr = 120;
-    uint8_t              mul(uint8_t a, uint8_t b) const { return (a && b) ? exp_[log_[a] + log_[b]] : 0; }
-    uint8_t              mul_exp(uint8_t a, int e) const { return a ? exp_[log_[a] + e] : 0; }
-    uint8_t              div(uint8_t a, uint8_t b) const { return a ? exp_[log_[a] + 255 - log_[b]] : 0; }
-    int                  nroots_, pad_;
-    uint8_t              exp_[510];
-    int                  log_[256];
-};
-
-struct Fec
-{
-    ReedSolomon adsb_short{12, 225}, adsb_long{14, 207}, uplink{20, 163};
-};
-const Fec& fec()
-{
-    static const Fec f;
-    return f;
+        RsTables x;
+        rs978_build_tables(x);
+        return x;
+    }();
+    return t;
 }
 
-constexpr int      kShortSkip = 36 + 240, kLongSkip = 36 + 384, kUplinkSkip = 36 + kUatUplinkBits;
 constexpr uint32_t kCheckMask = (1u << kUatCheckBits) - 1u;
 constexpr uint32_t kCheckAdsb = (uint32_t)(0xEACDDA4E2ull >> 18), kCheckUplink = (uint32_t)(0x153225B1Dull >> 18);
-
-// correct_adsb_frame: long first, in place; then short on whatever the long attempt left.  skip in bits, 0 = neither.
-int correct_adsb(uint8_t* f, int* rs)
-{
-    int n = fec().adsb_long.decode(f);
-    if (n >= 0 && n <= 7 && (f[0] >> 3) != 0)
-    {
-        *rs = n;
-        return kLongSkip;
-    }
-    n = fec().adsb_short.decode(f);
-    if (n >= 0 && n <= 6 && (f[0] >> 3) == 0)
-    {
-        *rs = n;
-        return kShortSkip;
-    }
-    *rs = 9999;
-    return 0;
-}
-
-int correct_uplink(const uint8_t* raw, uint8_t* out, int* rs)
-{
-    int total = 0;
-    for (int block = 0; block < 6; block++)
-    {
-        uint8_t cw[92];
-        for (int i = 0; i < 92; i++) cw[i] = raw[i * 6 + block];
-        const int n = fec().uplink.decode(cw);
-        if (n < 0 || n > 10)
-        {
-            *rs = 9999;
-            return 0;
-        }
-        total += n;
-        std::memcpy(out + block * 72, cw, 72);
-    }
-    *rs = total;
-    return kUplinkSkip;
-}
 
 #define UAT_HIP(expr)                                                        \
     do                                                                       \
@@ -214,6 +59,30 @@ int correct_uplink(const uint8_t* raw, uint8_t* out, int* rs)
     } while (0)
 
 thread_local std::string g_uat_create_error;
+
+// pinned host array that only grows
+template <class T>
+struct Pinned
+{
+    T*     p   = nullptr;
+    size_t cap = 0;
+    ~Pinned()
+    {
+        if (p) (void)hipHostFree(p);
+    }
+    hipError_t reserve(size_t n, size_t keep)
+    {
+        if (n <= cap) return hipSuccess;
+        T*         q = nullptr;
+        size_t     c = std::max(n, cap * 2);
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&q), c * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (keep) std::memcpy(q, p, keep * sizeof(T));
+        if (p) (void)hipHostFree(p);
+        p = q, cap = c;
+        return hipSuccess;
+    }
+};
 } // namespace
 
 struct adsb_amd_uat
@@ -223,23 +92,26 @@ struct adsb_amd_uat
     hipEvent_t  ev[4]  = {nullptr, nullptr, nullptr, nullptr};
     std::string error;
 
-    uint16_t* lut_d = nullptr;
+    uint16_t*             lut_d = nullptr;
+    RsTables*             rs_d  = nullptr;
     std::vector<uint16_t> lut_h;
 
     // scratch sized to the largest stream seen
-    uint64_t*         signs_d = nullptr;
-    size_t            signs_words = 0;
-    uint32_t*         cand_d = nullptr;
-    uint32_t          cand_cap = 0;
-    uint32_t*         counts_d = nullptr;
-    uint32_t*         counts_h = nullptr; // pinned
-    uat_adsb_rec_t*   adsb_d = nullptr;
-    uat_uplink_rec_t* uplink_d = nullptr;
-    uint32_t          uplink_cap = 0;
-    std::vector<uat_adsb_rec_t>   adsb_h;
-    std::vector<uat_uplink_rec_t> uplink_h;
-    std::unordered_map<uint64_t, uint32_t> by_key; // (index << 1 | kind) -> record
-    uint32_t nrecords = 0, nuplink = 0;
+    uint64_t*  signs_d = nullptr;
+    size_t     signs_words = 0;
+    uint32_t*  cand_d = nullptr;
+    uint32_t   cand_cap = 0;
+    uint32_t*  counts_d = nullptr;
+    uint32_t*  counts_h = nullptr; // pinned
+    uat_rec_t* recs_d = nullptr;
+    uint8_t*   up_d = nullptr; // decoded uplink payloads, 432 bytes per slot
+    uint32_t   up_cap = 0;
+    Pinned<uat_rec_t> recs_h;
+    Pinned<uint8_t>   up_h;
+    Pinned<uint32_t>  cand_h;
+    std::vector<uint64_t> order;                  // main matches: (index << 33 | kind << 32 | record), sorted
+    std::unordered_map<uint64_t, uint32_t> extra; // positions asked for on top of those: (index << 1 | kind) -> record
+    uint32_t nrecords = 0, nmain = 0, nuplink = 0;
 
     // input staging for host buffers
     uint8_t* in_d = nullptr;
@@ -252,14 +124,14 @@ struct adsb_amd_uat
     uint64_t  offset = 0;
     int       carry_full = 0;
 
-    float    scan_ms = 0.f, demod_ms = 0.f;
+    float    scan_ms = 0.f, demod_ms = 0.f, host_ms = 0.f;
     uint64_t stat_candidates = 0, stat_extra = 0;
 
     ~adsb_amd_uat()
     {
         (void)hipSetDevice(device);
-        for (void* p : {(void*)lut_d, (void*)signs_d, (void*)cand_d, (void*)counts_d, (void*)adsb_d, (void*)uplink_d, (void*)in_d, (void*)stage_d,
-                        (void*)stage_tmp_d})
+        for (void* p : {(void*)lut_d, (void*)rs_d, (void*)signs_d, (void*)cand_d, (void*)counts_d, (void*)recs_d, (void*)up_d, (void*)in_d,
+                        (void*)stage_d, (void*)stage_tmp_d})
             if (p) (void)hipFree(p);
         if (counts_h) (void)hipHostFree(counts_h);
         for (auto e : ev)
@@ -283,6 +155,8 @@ struct adsb_amd_uat
             }
         UAT_HIP(hipMalloc(&lut_d, 65536 * sizeof(uint16_t)));
         UAT_HIP(hipMemcpy(lut_d, lut_h.data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice));
+        UAT_HIP(hipMalloc(&rs_d, sizeof(RsTables)));
+        UAT_HIP(hipMemcpy(rs_d, &rs_tables(), sizeof(RsTables), hipMemcpyHostToDevice));
         UAT_HIP(hipMalloc(&counts_d, 2 * sizeof(uint32_t)));
         UAT_HIP(hipHostMalloc(&counts_h, 2 * sizeof(uint32_t)));
         UAT_HIP(hipMalloc(&stage_d, 65536 * sizeof(uint16_t)));
@@ -291,52 +165,63 @@ struct adsb_amd_uat
         return ADSB_AMD_OK;
     }
 
-    int reserve(uint64_t nsamples, uint32_t want_cand, uint32_t want_uplink)
+    int fail(int code, const char* msg)
+    {
+        error = msg;
+        return code;
+    }
+
+    int reserve_signs(uint64_t nsamples)
     {
         const size_t words = (size_t)((nsamples + 63) / 64) + 2;
-        if (words > signs_words)
-        {
-            if (signs_d) (void)hipFree(signs_d);
-            signs_d = nullptr, signs_words = 0;
-            UAT_HIP(hipMalloc(&signs_d, words * sizeof(uint64_t)));
-            signs_words = words;
-        }
-        if (want_cand > cand_cap)
-        {
-            if (cand_d) (void)hipFree(cand_d);
-            if (adsb_d) (void)hipFree(adsb_d);
-            cand_d = nullptr, adsb_d = nullptr, cand_cap = 0;
-            UAT_HIP(hipMalloc(&cand_d, (size_t)want_cand * sizeof(uint32_t)));
-            UAT_HIP(hipMalloc(&adsb_d, (size_t)want_cand * sizeof(uat_adsb_rec_t)));
-            cand_cap = want_cand;
-        }
-        if (want_uplink > uplink_cap)
-        {
-            if (uplink_d) (void)hipFree(uplink_d);
-            uplink_d = nullptr, uplink_cap = 0;
-            UAT_HIP(hipMalloc(&uplink_d, (size_t)want_uplink * sizeof(uat_uplink_rec_t)));
-            uplink_cap = want_uplink;
-        }
+        if (words <= signs_words) return ADSB_AMD_OK;
+        if (signs_d) (void)hipFree(signs_d);
+        signs_d = nullptr, signs_words = 0;
+        UAT_HIP(hipMalloc(&signs_d, words * sizeof(uint64_t)));
+        signs_words = words;
+        return ADSB_AMD_OK;
+    }
+    // the device arrays only receive; what the host still needs of them has been copied out before they are replaced
+    int reserve_cand(uint32_t want)
+    {
+        if (want <= cand_cap) return ADSB_AMD_OK;
+        if (cand_d) (void)hipFree(cand_d);
+        if (recs_d) (void)hipFree(recs_d);
+        cand_d = nullptr, recs_d = nullptr, cand_cap = 0;
+        UAT_HIP(hipMalloc(&cand_d, (size_t)want * sizeof(uint32_t)));
+        UAT_HIP(hipMalloc(&recs_d, (size_t)want * sizeof(uat_rec_t)));
+        cand_cap = want;
+        return ADSB_AMD_OK;
+    }
+    int reserve_uplink(uint32_t want)
+    {
+        if (want <= up_cap) return ADSB_AMD_OK;
+        if (up_d) (void)hipFree(up_d);
+        up_d = nullptr, up_cap = 0;
+        UAT_HIP(hipMalloc(&up_d, (size_t)want * 432));
+        up_cap = want;
         return ADSB_AMD_OK;
     }
 
     UatArgs args(const uint16_t* in, uint64_t n, bool phases_given) const
     {
         UatArgs a{};
-        a.in = in, a.lut = lut_d, a.nsamples = n, a.phases_given = phases_given ? 1 : 0;
+        a.in = in, a.lut = lut_d, a.rs_tables = rs_d, a.nsamples = n, a.phases_given = phases_given ? 1 : 0;
         a.signs = signs_d, a.cand = cand_d, a.cand_cap = cand_cap, a.counts = counts_d;
-        a.adsb = adsb_d, a.uplink = uplink_d, a.uplink_cap = uplink_cap;
+        a.recs = recs_d, a.uplink_payloads = up_d, a.uplink_cap = up_cap;
         return a;
     }
 
-    // GPU part of one process_buffer: after this adsb_h / uplink_h hold one record per exact 18-bit match
+    // GPU part of one process_buffer: afterwards recs_h holds one record per exact 18-bit match and `order` sorts them
     int scan(const uint16_t* in_dev, uint64_t n, bool phases_given)
     {
         if (n >= (1ull << 31)) return fail(ADSB_AMD_EINVAL, "UAT stream longer than 2^31 samples per call");
-        int rc = reserve(phases_given ? n : 0, std::max<uint32_t>(cand_cap, 4096), std::max<uint32_t>(uplink_cap, 1024)); // sign words: phases path only
+        int rc = phases_given ? reserve_signs(n) : ADSB_AMD_OK;
+        if (!rc) rc = reserve_cand(std::max<uint32_t>(cand_cap, 4096));
         if (rc) return rc;
-        nrecords = nuplink = 0;
-        by_key.clear();
+        nrecords = nmain = nuplink = 0;
+        extra.clear();
+        order.clear();
         for (int attempt = 0;; attempt++)
         {
             const UatArgs a = args(in_dev, n, phases_given);
@@ -346,50 +231,50 @@ struct adsb_amd_uat
             UAT_HIP(hipMemcpyAsync(counts_h, counts_d, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             UAT_HIP(hipStreamSynchronize(stream));
             const uint32_t ncand = counts_h[0];
-            if (ncand > cand_cap)
-            { // the match kernel counted past the array: grow and repeat the match
+            if (ncand + 64 > cand_cap)
+            { // the match kernel counted past the array (or left no room for later look-ups): grow and repeat the match
                 if (attempt > 2) return fail(ADSB_AMD_EHIP, "UAT candidate count keeps changing");
-                rc = reserve(0, ncand + ncand / 4 + 64, uplink_cap);
+                rc = reserve_cand(ncand + ncand / 4 + 256);
                 if (rc) return rc;
                 continue;
             }
-            if (ncand > uplink_cap)
-            {
-                rc = reserve(0, cand_cap, ncand + 64);
-                if (rc) return rc;
-            }
             stat_candidates += ncand;
-            rc = demod_on_device(in_dev, n, phases_given, ncand, 0);
+            rc = reserve_uplink(2 * ncand + 64); // at most two decoded payloads per match
+            if (!rc) rc = demod_on_device(in_dev, n, phases_given, ncand, 0);
             if (rc) return rc;
+            nmain = ncand;
             UAT_HIP(hipEventElapsedTime(&scan_ms, ev[0], ev[1]));
+            order.resize(ncand);
+            for (uint32_t k = 0; k < ncand; k++) order[k] = ((uint64_t)recs_h.p[k].index << 33) | ((uint64_t)recs_h.p[k].kind << 32) | k;
+            std::sort(order.begin(), order.end());
             return ADSB_AMD_OK;
         }
     }
 
-    // run K3 over cand_d[first .. first + count) and append the records to adsb_h / uplink_h
+    // run K3 over cand_d[first .. first + count) and append the records to recs_h / up_h
     int demod_on_device(const uint16_t* in_dev, uint64_t n, bool phases_given, uint32_t count, uint32_t first)
     {
         if (count == 0) return ADSB_AMD_OK;
         UatArgs a = args(in_dev, n, phases_given);
         a.cand += first;
-        a.adsb += first;
+        a.recs += first;
+        UAT_HIP(recs_h.reserve((size_t)first + count, first));
         UAT_HIP(hipEventRecord(ev[2], stream));
         UAT_HIP(launch_uat978_demod(a, count, stream));
         UAT_HIP(hipEventRecord(ev[3], stream));
         UAT_HIP(hipMemcpyAsync(counts_h + 1, counts_d + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        adsb_h.resize((size_t)first + count);
-        UAT_HIP(hipMemcpyAsync(adsb_h.data() + first, adsb_d + first, (size_t)count * sizeof(uat_adsb_rec_t), hipMemcpyDeviceToHost, stream));
+        UAT_HIP(hipMemcpyAsync(recs_h.p + first, recs_d + first, (size_t)count * sizeof(uat_rec_t), hipMemcpyDeviceToHost, stream));
         UAT_HIP(hipStreamSynchronize(stream));
         const uint32_t up_total = counts_h[1];
-        if (up_total > uplink_cap) return fail(ADSB_AMD_EHIP, "UAT uplink record area too small");
+        if (up_total > up_cap) return fail(ADSB_AMD_EHIP, "UAT uplink payload area too small");
         if (up_total > nuplink)
         {
-            uplink_h.resize(up_total);
-            UAT_HIP(hipMemcpy(uplink_h.data() + nuplink, uplink_d + nuplink, (size_t)(up_total - nuplink) * sizeof(uat_uplink_rec_t),
-                              hipMemcpyDeviceToHost));
+            UAT_HIP(up_h.reserve((size_t)up_total * 432, (size_t)nuplink * 432));
+            UAT_HIP(hipMemcpyAsync(up_h.p + (size_t)nuplink * 432, up_d + (size_t)nuplink * 432, (size_t)(up_total - nuplink) * 432,
+                                   hipMemcpyDeviceToHost, stream));
+            UAT_HIP(hipStreamSynchronize(stream));
             nuplink = up_total;
         }
-        for (uint32_t k = first; k < first + count; k++) by_key[((uint64_t)adsb_h[k].index << 1) | adsb_h[k].kind] = k;
         nrecords = first + count;
         float ms = 0.f;
         UAT_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));
@@ -401,47 +286,37 @@ struct adsb_amd_uat
     // stream (possible only through stale register bits right after a jump)
     int record_for(const uint16_t* in_dev, uint64_t n, bool phases_given, uint32_t index, uint32_t kind, uint32_t* out)
     {
-        auto it = by_key.find(((uint64_t)index << 1) | kind);
-        if (it != by_key.end())
+        const uint64_t key = ((uint64_t)index << 33) | ((uint64_t)kind << 32);
+        auto           it  = std::lower_bound(order.begin(), order.end(), key);
+        if (it != order.end() && (*it >> 32) == (key >> 32))
         {
-            *out = it->second;
+            *out = (uint32_t)*it;
             return ADSB_AMD_OK;
         }
-        if (nrecords + 1 > cand_cap || nuplink + 1 > uplink_cap)
-        { // grow, keeping what is there (rare path; host copies are authoritative, the device arrays only receive)
-            int rc = grow_keep();
-            if (rc) return rc;
+        auto ex = extra.find(((uint64_t)index << 1) | kind);
+        if (ex != extra.end())
+        {
+            *out = ex->second;
+            return ADSB_AMD_OK;
         }
-        const uint32_t raw = (index & 0x7FFFFFFFu) | (kind << 31);
-        UAT_HIP(hipMemcpyAsync(cand_d + nrecords, &raw, sizeof(raw), hipMemcpyHostToDevice, stream));
+        if (nrecords + 1 > cand_cap || nuplink + 2 > up_cap)
+        { // replace the device arrays by larger ones (host copies are complete); the slot counter keeps counting
+            const uint32_t keep_up = nuplink;
+            int            rc      = reserve_cand(cand_cap * 2 + 64);
+            if (!rc) rc = reserve_uplink(up_cap * 2 + 64);
+            if (rc) return rc;
+            (void)keep_up;
+        }
+        const uint32_t word = (index & 0x7FFFFFFFu) | (kind << 31);
+        UAT_HIP(hipMemcpyAsync(cand_d + nrecords, &word, sizeof(word), hipMemcpyHostToDevice, stream));
         UAT_HIP(hipStreamSynchronize(stream));
         stat_extra++;
         const uint32_t at = nrecords;
         int            rc = demod_on_device(in_dev, n, phases_given, 1, at);
         if (rc) return rc;
-        *out = at;
+        extra[((uint64_t)index << 1) | kind] = at;
+        *out                                 = at;
         return ADSB_AMD_OK;
-    }
-
-    int grow_keep()
-    {
-        // new arrays twice the size; device contents are not needed again (records already copied to the host), but the
-        // uplink counter keeps counting from nuplink so new records land behind the old ones
-        uint32_t* oc = cand_d;
-        auto*     oa = adsb_d;
-        auto*     ou = uplink_d;
-        cand_d = nullptr, adsb_d = nullptr, uplink_d = nullptr;
-        const uint32_t nc = cand_cap * 2 + 64, nu = uplink_cap * 2 + 64;
-        cand_cap = uplink_cap = 0;
-        int rc = reserve(0, nc, nu);
-        (void)hipFree(oc), (void)hipFree(oa), (void)hipFree(ou);
-        return rc;
-    }
-
-    int fail(int code, const char* msg)
-    {
-        error = msg;
-        return code;
     }
 
     // ---------------------------------------------------------------------------------------------------------------
@@ -449,45 +324,29 @@ struct adsb_amd_uat
     // ---------------------------------------------------------------------------------------------------------------
     struct Attempt
     {
-        int     skip = 0, rs = 9999, len = 0, variant = 0;
-        uint8_t data[432];
+        int            skip = 0, rs = 9999, len = 0, variant = 0;
+        const uint8_t* data = nullptr;
     };
 
-    // demod_*_frame at index and index + 1, then the reference's choice between them
-    bool attempt(const uat_adsb_rec_t& r, Attempt& best)
+    // demod_*_frame at index and index + 1 happened on the device; this is the reference's choice between them
+    bool attempt(const uat_rec_t& r, Attempt& best) const
     {
-        int     skip[2] = {0, 0}, rs[2] = {-1, -1};
-        uint8_t buf[2][432];
-        for (int v = 0; v < 2; v++)
-        {
-            if (r.kind == 0)
-            {
-                if (!r.ok[v])
-                {
-                    rs[v] = 9999;
-                    continue;
-                }
-                std::memcpy(buf[v], r.frame[v], kUatLongBytes);
-                skip[v] = correct_adsb(buf[v], &rs[v]);
-            }
-            else
-            {
-                const uat_uplink_rec_t& u = uplink_h[r.uplink_slot];
-                if (!u.ok[v])
-                {
-                    rs[v] = 9999;
-                    continue;
-                }
-                skip[v] = correct_uplink(u.frame[v], buf[v], &rs[v]);
-            }
-        }
-        int v;
-        if (skip[0] && rs[0] <= rs[1]) v = 0;
-        else if (skip[1] && rs[1] <= rs[0]) v = 1;
+        const int skip0 = r.skip[0], skip1 = r.skip[1], rs0 = r.rs[0], rs1 = r.rs[1];
+        int       v;
+        if (skip0 && rs0 <= rs1) v = 0;
+        else if (skip1 && rs1 <= rs0) v = 1;
         else return false;
-        best.skip = skip[v], best.rs = rs[v], best.variant = v;
-        best.len = r.kind ? 432 : ((buf[v][0] >> 3) == 0 ? 18 : 34);
-        std::memcpy(best.data, buf[v], (size_t)best.len);
+        best.skip = r.skip[v], best.rs = r.rs[v], best.variant = v;
+        if (r.kind)
+        {
+            best.len  = 432;
+            best.data = up_h.p + (size_t)r.slot[v] * 432;
+        }
+        else
+        {
+            best.len  = (r.payload[v][0] >> 3) == 0 ? 18 : 34;
+            best.data = r.payload[v];
+        }
         return true;
     }
 
@@ -505,14 +364,10 @@ struct adsb_amd_uat
         if (rc) return rc;
         const int64_t lenbits = (int64_t)(len / 2) - (kUatSyncBits + kUatUplinkBits);
 
-        // exact matches in stream order, grouped by start bit
-        std::vector<uint32_t> order(nrecords);
-        for (uint32_t k = 0; k < nrecords; k++) order[k] = k;
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return adsb_h[x].index < adsb_h[y].index; });
-
         int64_t bit = 0; // next bit the loop will examine
         size_t  pos = 0;
-        auto emit = [&](const uat_adsb_rec_t& r, const Attempt& a)
+        auto rec_at  = [&](size_t k) -> const uat_rec_t& { return recs_h.p[(uint32_t)order[k]]; };
+        auto emit = [&](const uat_rec_t& r, const Attempt& a)
         {
             if (cb) cb(user, r.kind ? '+' : '-', a.data, a.len, a.rs, stream_offset + r.index + (uint64_t)a.variant);
         };
@@ -520,23 +375,23 @@ struct adsb_amd_uat
         while (bit < lenbits)
         {
             // --- registers hold only stream bits: the loop fires exactly at the device's matches
-            while (pos < order.size() && (int64_t)(adsb_h[order[pos]].index >> 1) + 17 < std::max<int64_t>(bit, kUatCheckBits)) pos++;
+            while (pos < order.size() && (int64_t)(rec_at(pos).index >> 1) + 17 < std::max<int64_t>(bit, kUatCheckBits)) pos++;
             if (pos >= order.size()) break;
-            const int64_t startbit = adsb_h[order[pos]].index >> 1;
+            const int64_t startbit = rec_at(pos).index >> 1;
             if (startbit + 17 >= lenbits) break;
             // matches at this start bit: even/odd sample, ADS-B/uplink word
-            const uat_adsb_rec_t* m[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // [kind][alignment]
-            size_t                q       = pos;
-            for (; q < order.size() && (int64_t)(adsb_h[order[q]].index >> 1) == startbit; q++)
+            const uat_rec_t* m[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // [kind][alignment]
+            size_t           q       = pos;
+            for (; q < order.size() && (int64_t)(rec_at(q).index >> 1) == startbit; q++)
             {
-                const uat_adsb_rec_t& r = adsb_h[order[q]];
-                m[r.kind][r.index & 1]  = &r;
+                const uat_rec_t& r     = rec_at(q);
+                m[r.kind][r.index & 1] = &r;
             }
             pos = q;
             bit = startbit + 17; // the loop is at this bit now
-            const int             kind = (m[0][0] || m[0][1]) ? 0 : 1; // `else if`: the uplink word is only looked at without an ADS-B match
-            const uat_adsb_rec_t* r    = m[kind][0] ? m[kind][0] : m[kind][1];
-            Attempt               a;
+            const int        kind = (m[0][0] || m[0][1]) ? 0 : 1; // `else if`: the uplink word is only looked at without an ADS-B match
+            const uat_rec_t* r    = m[kind][0] ? m[kind][0] : m[kind][1];
+            Attempt          a;
             if (!attempt(*r, a))
             {
                 bit++;
@@ -545,11 +400,11 @@ struct adsb_amd_uat
             emit(*r, a);
             // --- jump: bit = startbit + skip, then the loop's ++.  The registers keep their contents, so for the next 17 bits
             // they mix bits from before the jump with new ones and can fire where the stream itself has no match.
-            uint32_t reg[2]  = {reg_from_window(r->window, 0), reg_from_window(r->window, 1)};
-            uint64_t fresh   = r->kind ? r->after[0] : (a.skip == kShortSkip ? r->after[0] : r->after[1]);
-            bit              = startbit + a.skip + 1;
+            uint32_t reg[2]     = {reg_from_window(r->window, 0), reg_from_window(r->window, 1)};
+            uint64_t fresh      = (r->kind || a.skip == kUatShortSkip) ? r->after[0] : r->after[1];
+            bit                 = startbit + a.skip + 1;
             int64_t mixed_until = bit + 17; // first bit at which both registers hold 18 new bits again
-            int     t        = 0;
+            int     t           = 0;
             while (bit < lenbits && bit < mixed_until)
             {
                 reg[0] = ((reg[0] << 1) | (uint32_t)((fresh >> (2 * t)) & 1u)) & kCheckMask;
@@ -569,15 +424,15 @@ struct adsb_amd_uat
                 uint32_t       at    = 0;
                 rc                   = record_for(in_dev, len, phases_given, index, k2, &at);
                 if (rc) return rc;
-                const uat_adsb_rec_t r2 = adsb_h[at]; // copy: adsb_h may grow below
-                Attempt              a2;
+                const uat_rec_t& r2 = recs_h.p[at];
+                Attempt          a2;
                 if (!attempt(r2, a2))
                 {
                     bit++;
                     continue;
                 }
                 emit(r2, a2);
-                fresh       = r2.kind ? r2.after[0] : (a2.skip == kShortSkip ? r2.after[0] : r2.after[1]);
+                fresh       = (r2.kind || a2.skip == kUatShortSkip) ? r2.after[0] : r2.after[1];
                 bit         = sb2 + a2.skip + 1;
                 mixed_until = bit + 17;
                 t           = 0;
@@ -723,10 +578,31 @@ extern "C" int adsb_amd_uat_phase_lut(const adsb_amd_uat_t* u, uint16_t* lut6553
     std::memcpy(lut65536, u->lut_h.data(), 65536 * sizeof(uint16_t));
     return ADSB_AMD_OK;
 }
+extern "C" int adsb_amd_uat_rs_decode_device(adsb_amd_uat_t* u, int kind, uint8_t* codewords, int count, int* results)
+{ // the decoder the demod kernel runs (whole wave on one code word), on `count` words of 30 / 48 / 92 bytes
+    if (!u || kind < 0 || kind > 2 || count < 0 || (count && (!codewords || !results))) return ADSB_AMD_EINVAL;
+    if (count == 0) return ADSB_AMD_OK;
+    if (hipSetDevice(u->device) != hipSuccess) return u->fail(ADSB_AMD_EHIP, "hipSetDevice failed");
+    const size_t bytes = (size_t)count * (kind == 0 ? 30 : kind == 1 ? 48 : 92);
+    uint8_t*     w_d   = nullptr;
+    int*         r_d   = nullptr;
+    auto&        error = u->error;
+    UAT_HIP(hipMalloc(&w_d, bytes));
+    UAT_HIP(hipMalloc(&r_d, (size_t)count * sizeof(int)));
+    hipError_t e = hipMemcpy(w_d, codewords, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_uat978_rs_selftest(u->rs_d, kind, w_d, r_d, count, u->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(u->stream);
+    if (e == hipSuccess) e = hipMemcpy(codewords, w_d, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(results, r_d, (size_t)count * sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(w_d), (void)hipFree(r_d);
+    UAT_HIP(e);
+    return ADSB_AMD_OK;
+}
 extern "C" int adsb_amd_uat_rs_decode(int kind, uint8_t* codeword)
-{
-    const ReedSolomon& rs = kind == 0 ? fec().adsb_short : kind == 1 ? fec().adsb_long : fec().uplink;
-    return rs.decode(codeword);
+{ // the decoder the device runs (rs978.h), compiled for the host: what the CPU tests hold against the oracle
+    RsWork w;
+    return kind == 0 ? rs978_decode(rs_tables(), 12, 225, codeword, 1, w)
+                     : kind == 1 ? rs978_decode(rs_tables(), 14, 207, codeword, 1, w) : rs978_decode(rs_tables(), 20, 163, codeword, 1, w);
 }
 
 // ---- the reference's C seam (UAT978.cpp:9-10): same names, same meaning.  dump_raw_message is the host's
@@ -753,7 +629,6 @@ extern "C" void adsb_amd_uat_set_dump_raw_message(adsb_amd_dump_raw_message_fn f
 extern "C" void init_fec(void)
 {
     std::lock_guard<std::mutex> lock(g_seam_mutex);
-    (void)fec();
     if (g_seam) return;
     adsb_amd_uat_t* u = nullptr;
     const char*     d = getenv("ADSB_AMD_DEVICE");

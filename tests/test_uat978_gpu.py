@@ -147,3 +147,27 @@ def test_device_resident_input(uat):
     assert got == O.process_buffer978(O.phase_lut978()[iq.view(np.uint16)])
     t = uat.timing()
     assert t["scan_ms"] > 0
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_device_reed_solomon_matches_oracle_including_beyond_capacity(uat, kind):
+    """The wave-wide decoder inside the demod kernel, on its own: clean, correctable, uncorrectable and random words."""
+    k, nr = {0: (18, 12), 1: (34, 14), 2: (72, 20)}[kind]
+    rng = np.random.default_rng(4242 + kind)
+    words = []
+    for trial in range(6000):
+        data = rng.integers(0, 256, k, dtype=np.uint8).tobytes()
+        cw = bytearray(data + O.rs_parity978(kind, data))
+        mode = trial % 6
+        if mode == 5:
+            cw = bytearray(rng.integers(0, 256, k + nr, dtype=np.uint8).tobytes())
+        else:
+            nerr = trial % (nr // 2 + 1) if mode == 0 else int(rng.integers(0, nr // 2 + 5))
+            for p in rng.choice(k + nr, nerr, replace=False):
+                cw[p] ^= int(rng.integers(1, 256))
+        words.append(bytes(cw))
+    arr = np.frombuffer(b"".join(words), dtype=np.uint8).reshape(len(words), k + nr)
+    res, fixed = uat.rs_decode_device(kind, arr)
+    for i, wd in enumerate(words):
+        n, out = O.rs_decode978(kind, wd)
+        assert (int(res[i]), fixed[i].tobytes()) == (n, out), i

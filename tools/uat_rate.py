@@ -27,10 +27,12 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cpu-mib", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cfg", default="", help="generator overrides, e.g. pct_corrupt=0,pct_uplink=0")
     a = ap.parse_args()
     piece = 64 << 20
     npieces = max(1, (a.mib << 20) // piece)
-    cfg = synth.default_cfg978()
+    over = {k: int(v) for k, v in (kv.split("=") for kv in a.cfg.split(",") if kv)}
+    cfg = synth.default_cfg978(**over)
     dev = torch.empty(npieces * piece, dtype=torch.uint8, device="cuda")
     first = None
     for k in range(npieces):
