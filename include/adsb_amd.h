@@ -200,6 +200,9 @@ int adsb_amd_uat_process_iq(adsb_amd_uat_t* u, const void* iq, uint64_t nsamples
 /* device time of the last process call (sign+match kernels, demod kernel) and running totals of 18-bit matches and of
  * positions the host had to ask the device about on top of those */
 int adsb_amd_uat_timing(const adsb_amd_uat_t* u, float* scan_ms, float* demod_ms, uint64_t* candidates, uint64_t* extra_lookups);
+/* host wall time of the last process call, by stage: launch..match count on the host, demod kernel..records on the host,
+ * ordering the records, the scan loop (including up-calls) */
+int adsb_amd_uat_host_timing(const adsb_amd_uat_t* u, float* match_ms, float* demod_ms, float* sort_ms, float* loop_ms);
 int adsb_amd_uat_phase_lut(const adsb_amd_uat_t* u, uint16_t* lut65536);  /* InitATan2Table, UAT978.cpp:76-100 */
 int adsb_amd_uat_rs_decode(int kind, uint8_t* codeword); /* 0 RS(30,18), 1 RS(48,34), 2 RS(92,72); in place; corrected count or -1 */
 /* the same on the GPU, with the decoder the demod kernel uses: `count` packed code words in place, one result each */

@@ -32,7 +32,7 @@ EXPORTS = [
     "adsb_amd_resolver_aircraft_count", "adsb_amd_handler_create", "adsb_amd_handler_destroy", "adsb_amd_handler_last_error",
     "adsb_amd_handler_set_sample_clock", "adsb_amd_handler_handle_data",
     "adsb_amd_uat_create", "adsb_amd_uat_destroy", "adsb_amd_uat_last_error", "adsb_amd_uat_handle_data", "adsb_amd_uat_set_carry_full",
-    "adsb_amd_uat_stream_state", "adsb_amd_uat_process_phases", "adsb_amd_uat_process_iq", "adsb_amd_uat_timing", "adsb_amd_uat_phase_lut",
+    "adsb_amd_uat_stream_state", "adsb_amd_uat_process_phases", "adsb_amd_uat_process_iq", "adsb_amd_uat_timing", "adsb_amd_uat_host_timing", "adsb_amd_uat_phase_lut",
     "adsb_amd_uat_rs_decode", "adsb_amd_uat_rs_decode_device", "adsb_amd_uat_set_dump_raw_message", "init_fec", "process_buffer",
 ]
 
@@ -93,6 +93,7 @@ def lib():
                                               C.POINTER(C.c_int64)]
         L.adsb_amd_uat_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.adsb_amd_uat_phase_lut.argtypes = [C.c_void_p, C.c_void_p]
+        L.adsb_amd_uat_host_timing.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 4
         L.adsb_amd_uat_rs_decode.argtypes = [C.c_int, C.c_void_p]
         L.adsb_amd_uat_rs_decode_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.adsb_amd_uat_set_dump_raw_message.argtypes = [C.c_void_p]
@@ -319,7 +320,10 @@ class Uat978:
     def timing(self):
         a, b, c, d = C.c_float(), C.c_float(), C.c_uint64(), C.c_uint64()
         self._l.adsb_amd_uat_timing(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
-        return {"scan_ms": a.value, "demod_ms": b.value, "candidates": c.value, "extra_lookups": d.value}
+        w = [C.c_float() for _ in range(4)]
+        self._l.adsb_amd_uat_host_timing(self._h, *[C.byref(x) for x in w])
+        return {"scan_ms": a.value, "demod_ms": b.value, "candidates": c.value, "extra_lookups": d.value,
+                "host_wall_ms": {"match": w[0].value, "demod": w[1].value, "sort": w[2].value, "loop": w[3].value}}
 
     def rs_decode_device(self, kind, words):
         """words: (count, 30 | 48 | 92) uint8 -> (results int32[count], corrected words)."""

@@ -185,22 +185,23 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
                                                                       uint32_t* __restrict__ count)
 {
     __shared__ uint16_t lut_s[65536];
-    __shared__ uint32_t sign_words[kUatChunkWords + 4]; // + 64 samples of halo (+ slack)
+    __shared__ uint32_t sign_words[2][kUatChunkWords + 4]; // two chunks in flight; + 64 samples of halo (+ slack) each
     // matches are parked here and flushed with ONE global atomic per ~512 of them: appending each match with its own
     // atomicAdd on the shared counter serialises in L2 (measured: 131 k matches per GiB cost 1.4 ms, the scan itself 0.25 ms)
     __shared__ uint32_t parked[kUatParkCap];
     __shared__ uint32_t parked_count, flush_base;
-    uint8_t* const      sign_bytes = reinterpret_cast<uint8_t*>(sign_words);
     const int           tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     for (int i = tid; i < 65536 / 8; i += kUatScanThreads) reinterpret_cast<uint4*>(lut_s)[i] = reinterpret_cast<const uint4*>(lut)[i];
-    if (tid < 4) sign_words[kUatChunkWords + tid] = 0;
+    if (tid < 8) sign_words[tid >> 2][kUatChunkWords + (tid & 3)] = 0;
     if (tid == 0) parked_count = 0;
     __syncthreads();
 
     const uint64_t nchunks = (n + kUatChunk - 1) / kUatChunk;
-    for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x)
+    // ---- A: signs of one chunk into sign buffer `buf`
+    auto phase_a = [&](uint64_t chunk, int buf)
     {
+        uint8_t* const sign_bytes = reinterpret_cast<uint8_t*>(sign_words[buf]);
         const uint64_t base = chunk * kUatChunk;
         // ---- A: signs.  Wave w owns samples [base + 2048 w, + 2048); wave 15 also does the halo, the 64 samples after the chunk.
         const uint64_t wave_start = base + (uint64_t)wave * kUatWaveSamples;
@@ -247,11 +248,14 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
             else byte = sign_byte_guarded(iq, lut_s, n, h0 + (uint64_t)(lane & 7) * 8);
             if (lane < 8) sign_bytes[kUatChunk / 8 + lane] = (uint8_t)byte;
         }
-        __syncthreads();
-        // ---- B: one word of 32 start positions per lane
+    };
+    // ---- B: one word of 32 start positions per lane
+    auto phase_b = [&](uint64_t chunk, int buf)
+    {
+        const uint64_t base = chunk * kUatChunk;
 #if !defined(UAT_EXP_NO_MATCH)
         {
-            const uint32_t w0 = sign_words[tid], w1 = sign_words[tid + 1], w2 = sign_words[tid + 2];
+            const uint32_t w0 = sign_words[buf][tid], w1 = sign_words[buf][tid + 1], w2 = sign_words[buf][tid + 2];
             uint32_t       all = 0xFFFFFFFFu, any = 0u; // over k of "bit k agrees with the ADS-B check word"
 #pragma unroll
             for (int k = 0; k < 18; k++)
@@ -285,6 +289,17 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
             }
         }
 #endif
+    };
+    // Software pipeline, one barrier per chunk: the signs of the next chunk are produced (global loads, LDS gathers) while
+    // the match of the current one runs, from the other sign buffer.
+    uint64_t chunk = blockIdx.x;
+    int      cur   = 0;
+    if (chunk < nchunks) phase_a(chunk, 0);
+    __syncthreads();
+    for (; chunk < nchunks; chunk += gridDim.x, cur ^= 1)
+    {
+        if (chunk + gridDim.x < nchunks) phase_a(chunk + gridDim.x, cur ^ 1);
+        phase_b(chunk, cur);
         __syncthreads();
         const uint32_t pending = parked_count < kUatParkCap ? parked_count : kUatParkCap; // same for every lane
         if (pending >= kUatParkCap / 2 || (pending && chunk + gridDim.x >= nchunks))

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -109,6 +110,7 @@ struct adsb_amd_uat
     Pinned<uat_rec_t> recs_h;
     Pinned<uint8_t>   up_h;
     Pinned<uint32_t>  cand_h;
+    std::vector<uint64_t> order_tmp;
     std::vector<uint64_t> order;                  // main matches: (index << 33 | kind << 32 | record), sorted
     std::unordered_map<uint64_t, uint32_t> extra; // positions asked for on top of those: (index << 1 | kind) -> record
     uint32_t nrecords = 0, nmain = 0, nuplink = 0;
@@ -124,7 +126,9 @@ struct adsb_amd_uat
     uint64_t  offset = 0;
     int       carry_full = 0;
 
-    float    scan_ms = 0.f, demod_ms = 0.f, host_ms = 0.f;
+    float    scan_ms = 0.f, demod_ms = 0.f;
+    float    wall_ms[4] = {0.f, 0.f, 0.f, 0.f}; // last process call: match (launch .. count on the host), demod (.. records on the host), sort, scan loop
+    static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     uint64_t stat_candidates = 0, stat_extra = 0;
 
     ~adsb_amd_uat()
@@ -222,6 +226,7 @@ struct adsb_amd_uat
         nrecords = nmain = nuplink = 0;
         extra.clear();
         order.clear();
+        const double t0 = now_ms();
         for (int attempt = 0;; attempt++)
         {
             const UatArgs a = args(in_dev, n, phases_given);
@@ -239,16 +244,37 @@ struct adsb_amd_uat
                 continue;
             }
             stat_candidates += ncand;
+            const double t1 = now_ms();
             rc = reserve_uplink(2 * ncand + 64); // at most two decoded payloads per match
             if (!rc) rc = demod_on_device(in_dev, n, phases_given, ncand, 0);
             if (rc) return rc;
             nmain = ncand;
             UAT_HIP(hipEventElapsedTime(&scan_ms, ev[0], ev[1]));
-            order.resize(ncand);
-            for (uint32_t k = 0; k < ncand; k++) order[k] = ((uint64_t)recs_h.p[k].index << 33) | ((uint64_t)recs_h.p[k].kind << 32) | k;
-            std::sort(order.begin(), order.end());
+            const double t2 = now_ms();
+            sort_main(ncand);
+            const double t3 = now_ms();
+            wall_ms[0] = (float)(t1 - t0), wall_ms[1] = (float)(t2 - t1), wall_ms[2] = (float)(t3 - t2);
             return ADSB_AMD_OK;
         }
+    }
+
+    // order[] = (index << 33 | kind << 32 | record) ascending: LSD radix sort over the 32 key bits that vary (index, kind)
+    void sort_main(uint32_t ncand)
+    {
+        order.resize(ncand);
+        order_tmp.resize(ncand);
+        for (uint32_t k = 0; k < ncand; k++) order[k] = ((uint64_t)recs_h.p[k].index << 33) | ((uint64_t)recs_h.p[k].kind << 32) | k;
+        uint64_t* src = order.data();
+        uint64_t* dst = order_tmp.data();
+        for (int shift = 32; shift < 64; shift += 11)
+        {
+            uint32_t hist[2049] = {0};
+            for (uint32_t k = 0; k < ncand; k++) hist[((src[k] >> shift) & 2047u) + 1]++;
+            for (int b = 0; b < 2048; b++) hist[b + 1] += hist[b];
+            for (uint32_t k = 0; k < ncand; k++) dst[hist[(src[k] >> shift) & 2047u]++] = src[k];
+            std::swap(src, dst);
+        }
+        if (src != order.data()) order.swap(order_tmp);
     }
 
     // run K3 over cand_d[first .. first + count) and append the records to recs_h / up_h
@@ -362,6 +388,7 @@ struct adsb_amd_uat
     {
         int rc = scan(in_dev, len, phases_given);
         if (rc) return rc;
+        const double  t_loop  = now_ms();
         const int64_t lenbits = (int64_t)(len / 2) - (kUatSyncBits + kUatUplinkBits);
 
         int64_t bit = 0; // next bit the loop will examine
@@ -440,6 +467,7 @@ struct adsb_amd_uat
         }
         if (bit < lenbits) bit = lenbits; // no further match: the loop runs to the end
         *consumed = lenbits > 0 ? (bit - kUatCheckBits) * 2 : (int64_t)-2 * kUatCheckBits;
+        wall_ms[3] = (float)(now_ms() - t_loop);
         return ADSB_AMD_OK;
     }
 
@@ -570,6 +598,15 @@ extern "C" int adsb_amd_uat_timing(const adsb_amd_uat_t* u, float* scan_ms, floa
     if (demod_ms) *demod_ms = u->demod_ms;
     if (candidates) *candidates = u->stat_candidates;
     if (extra_lookups) *extra_lookups = u->stat_extra;
+    return ADSB_AMD_OK;
+}
+extern "C" int adsb_amd_uat_host_timing(const adsb_amd_uat_t* u, float* match_ms, float* demod_ms, float* sort_ms, float* loop_ms)
+{
+    if (!u) return ADSB_AMD_EINVAL;
+    if (match_ms) *match_ms = u->wall_ms[0];
+    if (demod_ms) *demod_ms = u->wall_ms[1];
+    if (sort_ms) *sort_ms = u->wall_ms[2];
+    if (loop_ms) *loop_ms = u->wall_ms[3];
     return ADSB_AMD_OK;
 }
 extern "C" int adsb_amd_uat_phase_lut(const adsb_amd_uat_t* u, uint16_t* lut65536)

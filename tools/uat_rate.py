@@ -60,7 +60,7 @@ def main():
         "msamples_per_s_kernels": nsamples / ((min(scans) + min(demods)) * 1e-3) / 1e6,
         "msamples_per_s_wall": nsamples / min(walls) / 1e6,
         "hbm_read_gbs_sign_kernel_algorithmic": 2 * nsamples / (min(scans) * 1e-3) / 1e9,
-        "candidates_per_run": tm["candidates"] // (a.reps + 2), "extra_lookups": tm["extra_lookups"],
+        "candidates_per_run": tm["candidates"] // (a.reps + 2), "extra_lookups": tm["extra_lookups"], "host_wall_ms": tm["host_wall_ms"],
     }
     if not a.no_cpu:
         from oracle import oracle_py as O
