@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--cpu-buffers", type=int, default=4096, help="reference buffers in the CPU-baseline sample (0: skip)")
     ap.add_argument("--serial", action="store_true", help="submit/fetch one step at a time (no overlap of the record copy with the next "
                     "scan); used for rocprofv3 runs, where the runtime's shader-based copy would otherwise co-run with the scan kernel")
+    ap.add_argument("--workload", choices=["1090", "uat978"], default="1090", help="1090: the headline metric (BASELINE configs[1]+[2]); "
+                    "uat978: BASELINE configs[4], one independent stream per GPU (the UAT path does not shard: replicas only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,6 +101,9 @@ def main():
 
     import libadsb_amd as A
     from libadsb_amd import synth
+
+    if args.workload == "uat978":
+        return main_uat978(args, rank, local_rank, world, dist, A, synth)
 
     BB = A.REF_BUFFER_BYTES
     nbuf = (args.mib << 20) // BB
@@ -199,6 +204,98 @@ def main():
             out["cpu_baseline"] = cpu_baseline(iq_host, min(args.cpu_buffers, nbuf), BB)
         print(json.dumps(out), flush=True)
     sc.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_uat978(args, rank, local_rank, world, dist, A, synth):
+    """BASELINE configs[4]: UAT 978 u8 IQ (the reference's UAT input is u8, not i16) -> frames.  A step is one
+    process_buffer over the rank's whole device-resident stream: discriminator + sync search, sync re-check + slicing +
+    Reed-Solomon per match, records to the host, the host scan loop (no up-calls).  Streams are independent replicas."""
+    piece = 64 << 20
+    npieces = max(1, (args.mib << 20) // piece)
+    cfg = synth.default_cfg978()
+    dev = torch.empty(npieces * piece, dtype=torch.uint8, device="cuda")
+    first = None
+    for k in range(npieces):
+        h = synth.fill978(rank * npieces + k, piece, cfg)
+        first = h if first is None else first
+        dev[k * piece:(k + 1) * piece].copy_(torch.from_numpy(h))
+    torch.cuda.synchronize()
+    nsamples = dev.numel() // 2
+    u = A.Uat978(local_rank)
+
+    def run(steps):
+        scan = demod = 0.0
+        frames = 0
+        for _ in range(steps):
+            out, _ = u.process_device(dev.data_ptr(), nsamples, collect=False)
+            tm = u.timing()
+            scan += tm["scan_ms"]
+            demod += tm["demod_ms"]
+        return scan, demod
+
+    frames, consumed = u.process_device(dev.data_ptr(), nsamples)  # sizes the scratch; frame count for the report
+    if args.warmup > 0:
+        run(args.warmup)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    matches0 = u.timing()["candidates"]
+    t0 = time.perf_counter()
+    scan_ms, demod_ms = run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    matches = (u.timing()["candidates"] - matches0) // args.steps
+    nframes = len(frames)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([nframes], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        nframes_all = int(c.item())
+    else:
+        nframes_all = nframes
+    if rank == 0:
+        kernel_ms = scan_ms / args.steps
+        alg_bytes = 2.0 * nsamples
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        tm = u.timing()
+        out = {
+            "metric": "Msamples/s demodulated (UAT 978 u8 IQ -> Reed-Solomon-corrected frames)",
+            "value": round(nsamples * world * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8 in / u16 phase, GF(256) (bit-exact vs oracle)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: %d MiB synthetic UAT 978 u8 IQ per GPU (CPFSK h=0.6, 2 samples/bit, seed 0x978AD5B), "
+                                   "phase LUT + discriminator + 18-bit sync search + 36-bit sync re-check + slicing + RS(30,18)/RS(48,34)/"
+                                   "6xRS(92,72) on the GPU, dump978 scan-loop rules on the host; parity unpinned (dump978 is un-vendored)"
+                                   % (npieces * 64),
+                       "bytes_per_gpu": int(dev.numel()), "sharding": "replicas only: one independent stream per GPU, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "uat_scan_iq_kernel",
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": int(alg_bytes)},
+            "frames_per_step": nframes_all, "demod_kernel_ms": round(demod_ms / args.steps, 4), "matches_per_step_rank0": int(matches),
+            "host_wall_ms_last_step": tm["host_wall_ms"],
+        }
+        if world == 1 and args.cpu_buffers > 0:
+            from oracle import oracle_py as O
+            import numpy as np
+            phi = O.phase_lut978()[first.view(np.uint16)]
+            t1 = time.perf_counter()
+            want, _ = O.process_buffer978(phi)
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(first.size / 2 / dt / 1e6, 1), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                   "sample": "oracle978 process_buffer over the first 64 MiB of the same stream (%.2f s), LUT map excluded; %d frames"
+                                             % (dt, len(want))}
+        print(json.dumps(out), flush=True)
+    u.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
