@@ -83,6 +83,8 @@ def main():
                     "scan); used for rocprofv3 runs, where the runtime's shader-based copy would otherwise co-run with the scan kernel")
     ap.add_argument("--workload", choices=["1090", "uat978"], default="1090", help="1090: the headline metric (BASELINE configs[1]+[2]); "
                     "uat978: BASELINE configs[4], one independent stream per GPU (the UAT path does not shard: replicas only)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N > 1 ranks all on cuda:0 with the gloo backend: exercises the "
+                    "multi-rank code path (sharding, barrier, MAX/SUM reductions) on a one-GPU box; the numbers mean nothing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,12 +94,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: libadsb_amd has no CPU path")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import libadsb_amd as A
     from libadsb_amd import synth
