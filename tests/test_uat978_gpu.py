@@ -171,3 +171,18 @@ def test_device_reed_solomon_matches_oracle_including_beyond_capacity(uat, kind)
     for i, wd in enumerate(words):
         n, out = O.rs_decode978(kind, wd)
         assert (int(res[i]), fixed[i].tobytes()) == (n, out), i
+
+
+def test_process_iq_ragged_lengths_around_chunk_and_row_edges(uat):
+    """The fused kernel works in 32 768-sample chunks, 2 048-sample wave spans, 512-sample rows and a 64-sample halo; the
+    stream may end anywhere relative to those.  A frame is placed so that it ends just before the end of the stream."""
+    base = synth.fill978(21, 2 * 262144, synth.default_cfg978(mean_gap_bits=200))
+    lut = O.phase_lut978()
+    sizes = [0, 1, 2, 35, 36, 37, 511, 512, 513, 2047, 2048, 2049, 8903, 8906, 32767, 32768, 32769, 32768 + 63, 32768 + 64, 32768 + 65,
+             34815, 34816, 34817, 65535, 65536, 65537, 65536 + 2048 + 1, 98304, 98305, 131071, 200001, 262144]
+    for n in sizes:
+        iq = base[:2 * n]
+        want = O.process_buffer978(lut[iq.view(np.uint16)])
+        got = uat.process_iq(iq)
+        assert got == want, n
+    assert any(len(O.process_buffer978(lut[base[:2 * n].view(np.uint16)])[0]) > 0 for n in sizes)
