@@ -161,6 +161,12 @@ void        adsb_amd_handler_set_sample_clock(adsb_amd_handler_t* h, int64_t t0_
  * buffer_bytes as in adsb_amd_scan_1090 (0 = the reference's behaviour: one call, one buffer). */
 long adsb_amd_handler_handle_data(adsb_amd_handler_t* h, const uint8_t* iq_host, size_t nbytes, size_t buffer_bytes,
                                   adsb_amd_on_changed_fn cb, void* user);
+/* Recorded-file replay, one pass: what RTLSDR::TestDataReadLoop (RTLSDR.hpp:419-442) feeds a handler -- whole 262144-byte
+ * buffers in file order, each demodulated on its own, a trailing partial buffer never delivered -- over buffers
+ * [first_buffer, first_buffer + max_buffers) of the file (ranks of a multi-GPU job take disjoint ranges; the resolver state
+ * of this handler carries across the whole range).  Returns the number of accepted frames or a negative error. */
+long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* path, size_t first_buffer, size_t max_buffers, adsb_amd_on_changed_fn cb,
+                                  void* user);
 
 /* =====================================================================================================================
  * UAT 978.  Boundary replaced:

@@ -30,7 +30,7 @@ EXPORTS = [
     "adsb_amd_scan_1090_submit", "adsb_amd_scan_1090_fetch", "adsb_amd_scan_1090_timing", "adsb_amd_magnitude_1090",
     "adsb_amd_resolver_create", "adsb_amd_resolver_destroy", "adsb_amd_resolver_set_sample_clock", "adsb_amd_resolver_feed",
     "adsb_amd_resolver_aircraft_count", "adsb_amd_handler_create", "adsb_amd_handler_destroy", "adsb_amd_handler_last_error",
-    "adsb_amd_handler_set_sample_clock", "adsb_amd_handler_handle_data",
+    "adsb_amd_handler_set_sample_clock", "adsb_amd_handler_handle_data", "adsb_amd_handler_replay_file",
     "adsb_amd_uat_create", "adsb_amd_uat_destroy", "adsb_amd_uat_last_error", "adsb_amd_uat_handle_data", "adsb_amd_uat_set_carry_full",
     "adsb_amd_uat_stream_state", "adsb_amd_uat_process_phases", "adsb_amd_uat_process_iq", "adsb_amd_uat_timing", "adsb_amd_uat_host_timing", "adsb_amd_uat_phase_lut",
     "adsb_amd_uat_rs_decode", "adsb_amd_uat_rs_decode_device", "adsb_amd_uat_set_dump_raw_message", "init_fec", "process_buffer",
@@ -81,6 +81,8 @@ def lib():
         L.adsb_amd_handler_set_sample_clock.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
         L.adsb_amd_handler_handle_data.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
         L.adsb_amd_handler_handle_data.restype = C.c_long
+        L.adsb_amd_handler_replay_file.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.adsb_amd_handler_replay_file.restype = C.c_long
         L.adsb_amd_uat_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         L.adsb_amd_uat_destroy.argtypes = [C.c_void_p]
         L.adsb_amd_uat_last_error.argtypes = [C.c_void_p]
@@ -240,6 +242,17 @@ class Handler1090:
         if n < 0:
             raise AdsbAmdError("handle_data failed (%d): %s" % (n, self._l.adsb_amd_handler_last_error(self._h).decode()))
         return col.arrays()
+
+    def replay_file(self, path, first_buffer=0, max_buffers=2**62, collect=True):
+        """RTLSDR::TestDataReadLoop for one pass over a recorded u8 IQ file (whole 262144-B buffers).  Returns
+        (accepted frame count, frames, aircraft)."""
+        col = _Collector()
+        cb = C.cast(col.cb, C.c_void_p) if collect else None
+        n = self._l.adsb_amd_handler_replay_file(self._h, os.fsencode(path), first_buffer, max_buffers, cb, None)
+        if n < 0:
+            raise AdsbAmdError("replay_file failed (%d): %s" % (n, self._l.adsb_amd_handler_last_error(self._h).decode()))
+        fr, ac = col.arrays()
+        return n, fr, ac
 
 
 UAT_FRAME = C.CFUNCTYPE(None, C.c_void_p, C.c_char, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_uint64)

@@ -3,6 +3,14 @@
 // every entry point that needs the device fails with ADSB_AMD_ENODEV / ADSB_AMD_EHIP when HIP is unusable.
 #include <hip/hip_runtime_api.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -434,6 +442,62 @@ extern "C" long adsb_amd_handler_handle_data(adsb_amd_handler_t* h, const uint8_
     size_t spb  = a.nbuf ? a.buf_samples : nbytes / 2;
     size_t nbuf = a.nbuf ? a.nbuf : 1;
     return h->resolver.feed(rec, n, spb, nbuf, cb, user);
+}
+
+// Recorded-file replay: what RTLSDR::TestDataReadLoop (RTLSDR.hpp:419-442) does for a handler -- whole BufferLength
+// (262 144 B) reads in file order, each buffer demodulated on its own, a trailing partial read never delivered -- for one
+// pass over buffers [first_buffer, first_buffer + max_buffers) of the file (the reference re-opens the file and loops until
+// stopped; ranks of a multi-GPU job take disjoint ranges).  The file is mapped and handed to the batch path in slices.
+extern "C" long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* path, size_t first_buffer, size_t max_buffers,
+                                             adsb_amd_on_changed_fn cb, void* user)
+{
+    if (!h || !path) return ADSB_AMD_EINVAL;
+    h->error.clear();
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0)
+    {
+        h->error = std::string("cannot open ") + path + ": " + strerror(errno);
+        return ADSB_AMD_EINVAL;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0)
+    {
+        h->error = std::string("fstat ") + path + ": " + strerror(errno);
+        close(fd);
+        return ADSB_AMD_EINVAL;
+    }
+    const size_t BB    = ADSB_AMD_REF_BUFFER_BYTES;
+    const size_t total = (size_t)st.st_size / BB; // whole buffers only
+    if (first_buffer >= total || max_buffers == 0)
+    {
+        close(fd);
+        return 0;
+    }
+    const size_t nbuf = std::min(max_buffers, total - first_buffer);
+    void*        map  = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED)
+    {
+        h->error = std::string("mmap ") + path + ": " + strerror(errno);
+        return ADSB_AMD_EINVAL;
+    }
+    (void)madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
+    const uint8_t* base     = static_cast<const uint8_t*>(map) + first_buffer * BB;
+    const size_t   kSlice   = 1024; // buffers per batch (256 MiB)
+    long           accepted = 0;
+    for (size_t b = 0; b < nbuf; b += kSlice)
+    {
+        const size_t n  = std::min(kSlice, nbuf - b);
+        const long   rc = adsb_amd_handler_handle_data(h, base + b * BB, n * BB, BB, cb, user);
+        if (rc < 0)
+        {
+            accepted = rc;
+            break;
+        }
+        accepted += rc;
+    }
+    munmap(map, (size_t)st.st_size);
+    return accepted;
 }
 
 // ------------------------------------------------------------------------------------------------ resolver (host only)

@@ -174,3 +174,28 @@ def test_cxx_drop_in_handler_matches_reference_test_flow(native_libs, tmp_path):
         want = [t.encode("latin-1") for t in H.callback_text(oac)]
         assert got == want
         assert len(got) > 100
+
+
+def test_replay_file_matches_oracle_and_drops_the_partial_buffer(native_libs, tmp_path):
+    """Recorded-file replay (RTLSDR.hpp:419-442): whole 262144-B buffers in order, the trailing partial read is never
+    delivered; a rank's sub-range equals the same buffers handled alone."""
+    iq, _ = synth.fill_range(40, 6)
+    path = tmp_path / "1090000000.test.dat"
+    with open(path, "wb") as f:
+        f.write(iq.tobytes())
+        f.write(iq[:100001].tobytes())  # partial seventh buffer
+    h = A.Handler1090()
+    n, fr, ac = h.replay_file(str(path))
+    ofr, oac = H.oracle_run(iq, BB)
+    assert n == len(fr) == len(ofr) > 100
+    H.assert_streams_equal(fr, ac, ofr, oac)
+    h.close()
+    h = A.Handler1090()
+    n2, fr2, ac2 = h.replay_file(str(path), first_buffer=2, max_buffers=3)
+    ofr2, oac2 = H.oracle_run(iq[2 * BB:5 * BB], BB)
+    assert n2 == len(ofr2)
+    H.assert_streams_equal(fr2, ac2, ofr2, oac2)
+    assert h.replay_file(str(path), first_buffer=6)[0] == 0
+    with pytest.raises(A.AdsbAmdError, match="cannot open"):
+        h.replay_file(str(tmp_path / "missing.dat"))
+    h.close()
