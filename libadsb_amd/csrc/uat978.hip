@@ -157,8 +157,20 @@ __device__ __forceinline__ uint32_t sign_byte(uint32_t p01, uint32_t p23, uint32
     return acc >> 15;
 }
 
+// LDS bank of a LUT entry = bits 1..6 of its index = bits 1..6 of I alone (Q only moves the address by multiples of 512 B),
+// so samples that differ in Q but not in I pile onto one bank; receiver noise (I, Q within a few LSB of 127) uses ~4 of the
+// 64 banks.  The table is therefore stored with Q's low six bits XORed into those index bits (a bijection), and every
+// look-up applies the same XOR: one extra shift-and-mask and one XOR per two samples.
+#if !defined(UAT_EXP_NO_SWIZZLE)
+__device__ __forceinline__ uint32_t swz2(uint32_t iq2) { return iq2 ^ ((iq2 >> 7) & 0x007E007Eu); } // both u16 halves at once
+#else
+__device__ __forceinline__ uint32_t swz2(uint32_t iq2) { return iq2; }
+#endif
+__device__ __forceinline__ uint32_t swz1(uint32_t iq) { return swz2(iq) & 0xFFFFu; }
+
 __device__ __forceinline__ uint32_t lut2(const uint16_t* __restrict__ lut_s, uint32_t iq2)
 { // phases of the two samples in one dword, packed the same way
+    iq2 = swz2(iq2);
 #if defined(UAT_EXP_NO_GATHER)
     (void)lut_s;
     return iq2 * 0x9E3779B1u;
@@ -174,7 +186,7 @@ __device__ __forceinline__ uint8_t sign_byte_guarded(const uint16_t* __restrict_
 #pragma unroll
     for (int k = 0; k < 9; k++) raw[k] = iq[(s0 + (uint64_t)k < n) ? s0 + (uint64_t)k : n - 1];
 #pragma unroll
-    for (int k = 0; k < 9; k++) ph[k] = lut_s[raw[k]];
+    for (int k = 0; k < 9; k++) ph[k] = lut_s[swz1(raw[k])];
 #pragma unroll
     for (int k = 0; k < 8; k++) byte |= (s0 + (uint64_t)k + 1 < n && phi_difference(ph[k], ph[k + 1]) > 0) ? (1u << k) : 0u;
     return (uint8_t)byte;
@@ -192,7 +204,12 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
     __shared__ uint32_t parked_count, flush_base;
     const int           tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (int i = tid; i < 65536 / 8; i += kUatScanThreads) reinterpret_cast<uint4*>(lut_s)[i] = reinterpret_cast<const uint4*>(lut)[i];
+    for (int i = tid; i < 65536 / 2; i += kUatScanThreads)
+    { // two entries per lane per trip; they land swizzled
+        const uint32_t two = reinterpret_cast<const uint32_t*>(lut)[i];
+        lut_s[swz1(2u * (uint32_t)i)]      = (uint16_t)two;
+        lut_s[swz1(2u * (uint32_t)i + 1u)] = (uint16_t)(two >> 16);
+    }
     if (tid < 8) sign_words[tid >> 2][kUatChunkWords + (tid & 3)] = 0;
     if (tid == 0) parked_count = 0;
     __syncthreads();
@@ -221,7 +238,7 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
 #pragma unroll
             for (int r = 0; r < kUatRows; r++)
             { // a lane's ninth phase is the next lane's first (wave_shl:1); lane 63's is the next row's first
-                const uint32_t after = (r + 1 < kUatRows) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p01[(r + 1) % kUatRows]) : (uint32_t)lut_s[after_wave];
+                const uint32_t after = (r + 1 < kUatRows) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p01[(r + 1) % kUatRows]) : (uint32_t)lut_s[swz1(after_wave)];
                 const uint32_t p8    = (uint32_t)__builtin_amdgcn_update_dpp((int)after, (int)p01[r], 0x130, 0xF, 0xF, false);
                 sign_bytes[wave * (kUatWaveSamples / 8) + r * 64 + lane] = (uint8_t)sign_byte(p01[r], p23[r], p45[r], p67[r], p8 & 0xFFFFu);
             }
@@ -240,7 +257,7 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
                 uint4 v = {0, 0, 0, 0};
                 if (lane < 8) v = *reinterpret_cast<const uint4*>(iq + h0 + (uint64_t)lane * 8);
                 const uint32_t p01 = lut2(lut_s, v.x), p23 = lut2(lut_s, v.y), p45 = lut2(lut_s, v.z), p67 = lut2(lut_s, v.w);
-                const uint32_t after = lut_s[iq[h0 + 64]];
+                const uint32_t after = lut_s[swz1(iq[h0 + 64])];
                 uint32_t       p8    = (uint32_t)__builtin_amdgcn_update_dpp((int)after, (int)p01, 0x130, 0xF, 0xF, false);
                 if (lane == 7) p8 = after;
                 byte = sign_byte(p01, p23, p45, p67, p8 & 0xFFFFu);
