@@ -168,14 +168,32 @@ __device__ __forceinline__ uint32_t swz2(uint32_t iq2) { return iq2; }
 #endif
 __device__ __forceinline__ uint32_t swz1(uint32_t iq) { return swz2(iq) & 0xFFFFu; }
 
+// byte offset into the u16 table of the sample in the low / high half of `y`: one SDWA shift each (the compiler would
+// otherwise mask and shift separately, and fold the swizzle XOR into both halves' address computations)
+__device__ __forceinline__ uint32_t table_offset_lo(uint32_t y)
+{
+    uint32_t r;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(1u), "v"(y));
+    return r;
+}
+__device__ __forceinline__ uint32_t table_offset_hi(uint32_t y)
+{
+    uint32_t r;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(1u), "v"(y));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t lut2(const uint16_t* __restrict__ lut_s, uint32_t iq2)
 { // phases of the two samples in one dword, packed the same way
-    iq2 = swz2(iq2);
 #if defined(UAT_EXP_NO_GATHER)
     (void)lut_s;
     return iq2 * 0x9E3779B1u;
 #endif
-    return (uint32_t)lut_s[iq2 & 0xFFFFu] | ((uint32_t)lut_s[iq2 >> 16] << 16);
+    const uint32_t y  = swz2(iq2);
+    const char*    b  = reinterpret_cast<const char*>(lut_s);
+    const uint32_t lo = *reinterpret_cast<const uint16_t*>(b + table_offset_lo(y));
+    const uint32_t hi = *reinterpret_cast<const uint16_t*>(b + table_offset_hi(y));
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u); // hi.word0 : lo.word0
 }
 
 // the same byte for 8 samples from s0 on, anywhere relative to the end of the stream.  Branch-free on purpose: the nine
