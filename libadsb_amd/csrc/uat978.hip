@@ -32,6 +32,13 @@ __device__ __forceinline__ int phi_difference(uint32_t from, uint32_t to)
     return (int)(int16_t)(uint16_t)(to - from);
 }
 
+__device__ __forceinline__ void wave_lds_fence()
+{ // orders this wave's LDS traffic; no other wave touches the same words
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_or_zero_i(int v)
 {
@@ -113,21 +120,22 @@ __global__ __launch_bounds__(256) void uat_match_kernel(const uint64_t* __restri
 
 // ---- K1+K2 fused for u8 IQ input (the batch path): the discriminator and the sync search in one pass over HBM.
 // One 1024-lane workgroup per CU, persistent.  LDS holds the whole phase LUT (128 KiB; the IQ pair read as one u16 IS
-// the index, UAT978.cpp:52) plus one chunk's sign bits.  Per chunk of 32 768 samples:
-//   A  each wave takes 4 rows of 512 samples, 16 B (8 samples) per lane per row: 8 LDS gathers give the phases as packed
-//      u16 pairs, the pair shifted by one sample comes from v_alignbit, v_pk_sub_i16 is the wrapped difference of two
-//      samples at once, a saturating negate moves "difference > 0" into the sign bits and v_dot2 packs the 8 signs of a
-//      lane into a byte (sample order); the byte goes to LDS.  The phase of a lane's ninth sample is its neighbour's first.
+// the index, UAT978.cpp:52), shared read-only; everything else is private to a wave, so there is no barrier after the
+// table load.  A wave owns whole 2 048-sample spans (span s -> wave s mod nwaves):
+//   A  4 rows of 512 samples, 16 B (8 samples) per lane per row, plus 64 samples of halo on 8 lanes; the loads of the next
+//      span are issued before this one is worked on.  8 LDS gathers per lane per row give the phases as packed u16 pairs,
+//      the pair shifted by one sample comes from v_alignbit, v_pk_sub_i16 is the wrapped difference of two samples at
+//      once, a saturating negate moves "difference > 0" into the sign bits and v_dot2 packs the 8 signs of a lane into a
+//      byte (sample order); the byte goes to the wave's corner of LDS.  A lane's ninth phase is its neighbour's first.
 //   B  each lane takes one 32-sample word of sign bits plus the two words after it: 18 funnel shifts (the check bits sit
 //      two samples apart) shared by both sync words, which are bitwise complements of each other on their first 18 bits,
 //      so one AND chain and one OR chain decide both.
-// Algorithmic traffic: 2 B per sample, read once (+ 128 B of halo per chunk).
+// Algorithmic traffic: 2 B per sample, read once (+ 128 B of halo per 4 KiB span, which the neighbouring wave reads anyway).
 constexpr int kUatScanThreads = 1024, kUatScanWaves = kUatScanThreads / 64, kUatRows = 4;
 constexpr int kUatRowSamples  = 64 * 8;
 constexpr int kUatWaveSamples = kUatRows * kUatRowSamples;     // 2048
-constexpr int kUatChunk       = kUatScanWaves * kUatWaveSamples; // 32768 samples = 1024 sign words
-constexpr int kUatChunkWords  = kUatChunk / 32;
-constexpr uint32_t kUatParkCap = 1024;
+constexpr int kUatSpanWords   = kUatWaveSamples / 32; // 64: one per lane
+constexpr uint32_t kUatParkCap = 64;  // per wave
 static_assert((0xEACDDA4E2ull >> 18) == (~(0x153225B1Dull >> 18) & 0x3FFFFull), "the two check words are complements");
 
 __device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b)
@@ -214,13 +222,16 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
                                                                       uint64_t n, uint32_t* __restrict__ cand, uint32_t cap,
                                                                       uint32_t* __restrict__ count)
 {
+    // The workgroup shares only the (read-only) table.  Each wave owns whole 2 048-sample spans: it produces the span's sign
+    // bits plus 64 samples of halo into its own corner of LDS and searches them itself, so after the table is loaded no
+    // barrier is needed and the sixteen waves of a CU drift apart freely (loads of one under gathers and ALU of the others).
     __shared__ uint16_t lut_s[65536];
-    __shared__ uint32_t sign_words[2][kUatChunkWords + 4]; // two chunks in flight; + 64 samples of halo (+ slack) each
-    // matches are parked here and flushed with ONE global atomic per ~512 of them: appending each match with its own
+    __shared__ uint32_t sign_words[kUatScanWaves][kUatSpanWords + 4]; // + 2 halo words (+ slack)
+    // matches are parked per wave and flushed with ONE global atomic per ~32 of them: appending each match with its own
     // atomicAdd on the shared counter serialises in L2 (measured: 131 k matches per GiB cost 1.4 ms, the scan itself 0.25 ms)
-    __shared__ uint32_t parked[kUatParkCap];
-    __shared__ uint32_t parked_count, flush_base;
-    const int           tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t parked[kUatScanWaves][kUatParkCap];
+    __shared__ uint32_t parked_count[kUatScanWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     for (int i = tid; i < 65536 / 2; i += kUatScanThreads)
     { // two entries per lane per trip; they land swizzled
@@ -228,83 +239,95 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
         lut_s[swz1(2u * (uint32_t)i)]      = (uint16_t)two;
         lut_s[swz1(2u * (uint32_t)i + 1u)] = (uint16_t)(two >> 16);
     }
-    if (tid < 8) sign_words[tid >> 2][kUatChunkWords + (tid & 3)] = 0;
-    if (tid == 0) parked_count = 0;
+    if (lane < 4) sign_words[wave][kUatSpanWords + lane] = 0;
+    if (lane == 0) parked_count[wave] = 0;
     __syncthreads();
 
-    const uint64_t nchunks = (n + kUatChunk - 1) / kUatChunk;
-    // ---- A: signs of one chunk into sign buffer `buf`
-    auto phase_a = [&](uint64_t chunk, int buf)
+    uint32_t* const my_words  = sign_words[wave];
+    uint8_t* const  my_bytes  = reinterpret_cast<uint8_t*>(my_words);
+    uint32_t* const my_parked = parked[wave];
+    const uint64_t  nspans    = (n + kUatWaveSamples - 1) / kUatWaveSamples;
+    const uint64_t  nwaves    = (uint64_t)gridDim.x * kUatScanWaves;
+
+    auto flush = [&](uint32_t pending)
+    { // wave-wide; `pending` <= kUatParkCap entries of my_parked go to the global list
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(count, pending);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        for (uint32_t k = lane; k < pending; k += 64)
+            if (base + k < cap) cand[base + k] = my_parked[k];
+        wave_lds_fence();
+        if (lane == 0) parked_count[wave] = 0;
+        wave_lds_fence();
+    };
+
+    // span s of the stream belongs to wave (s mod nwaves): neighbouring waves read neighbouring 4 KiB
+    uint64_t span = (uint64_t)blockIdx.x * kUatScanWaves + (uint64_t)wave;
+    // register prefetch: the loads of the next span are issued before this one is worked on
+    uint4    v[kUatRows], vh = {0, 0, 0, 0};
+    uint32_t after_halo = 0;
+    auto     fast       = [&](uint64_t sp) { return sp < nspans && (sp + 1) * kUatWaveSamples + 64 + 1 <= n; };
+    auto     load       = [&](uint64_t sp)
     {
-        uint8_t* const sign_bytes = reinterpret_cast<uint8_t*>(sign_words[buf]);
-        const uint64_t base = chunk * kUatChunk;
-        // ---- A: signs.  Wave w owns samples [base + 2048 w, + 2048); wave 15 also does the halo, the 64 samples after the chunk.
-        const uint64_t wave_start = base + (uint64_t)wave * kUatWaveSamples;
-        if (wave_start + kUatWaveSamples + 1 <= n)
-        { // every difference has both samples: all four 16-byte loads in flight, then 32 gathers
-            uint4 v[kUatRows];
+        const uint64_t s0 = sp * kUatWaveSamples;
 #pragma unroll
-            for (int r = 0; r < kUatRows; r++) v[r] = *reinterpret_cast<const uint4*>(iq + wave_start + (uint64_t)r * kUatRowSamples + (uint64_t)lane * 8);
-            const uint32_t after_wave = iq[wave_start + kUatWaveSamples]; // uniform address
-            uint32_t       p01[kUatRows], p23[kUatRows], p45[kUatRows], p67[kUatRows];
+        for (int r = 0; r < kUatRows; r++) v[r] = *reinterpret_cast<const uint4*>(iq + s0 + (uint64_t)r * kUatRowSamples + (uint64_t)lane * 8);
+        vh         = *reinterpret_cast<const uint4*>(iq + s0 + kUatWaveSamples + (uint64_t)(lane & 7) * 8); // halo: lanes 0..7 matter
+        after_halo = iq[s0 + kUatWaveSamples + 64];
+    };
+    if (fast(span)) load(span);
+    for (; span < nspans; span += nwaves)
+    {
+        const uint64_t s0 = span * kUatWaveSamples;
+        // ---- A: sign bits of [s0, s0 + 2048 + 64)
+        if (fast(span))
+        {
+            uint32_t p01[kUatRows + 1], p23[kUatRows + 1], p45[kUatRows + 1], p67[kUatRows + 1];
 #pragma unroll
             for (int r = 0; r < kUatRows; r++)
             {
                 p01[r] = lut2(lut_s, v[r].x), p23[r] = lut2(lut_s, v[r].y);
                 p45[r] = lut2(lut_s, v[r].z), p67[r] = lut2(lut_s, v[r].w);
             }
+            p01[kUatRows] = lut2(lut_s, vh.x), p23[kUatRows] = lut2(lut_s, vh.y);
+            p45[kUatRows] = lut2(lut_s, vh.z), p67[kUatRows] = lut2(lut_s, vh.w);
+            const uint32_t after_all = lut_s[swz1(after_halo)];
+            if (fast(span + nwaves)) load(span + nwaves); // everything of this span is in registers as phases now
 #pragma unroll
-            for (int r = 0; r < kUatRows; r++)
-            { // a lane's ninth phase is the next lane's first (wave_shl:1); lane 63's is the next row's first
-                const uint32_t after = (r + 1 < kUatRows) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p01[(r + 1) % kUatRows]) : (uint32_t)lut_s[swz1(after_wave)];
-                const uint32_t p8    = (uint32_t)__builtin_amdgcn_update_dpp((int)after, (int)p01[r], 0x130, 0xF, 0xF, false);
-                sign_bytes[wave * (kUatWaveSamples / 8) + r * 64 + lane] = (uint8_t)sign_byte(p01[r], p23[r], p45[r], p67[r], p8 & 0xFFFFu);
+            for (int r = 0; r <= kUatRows; r++)
+            { // a lane's ninth phase is the next lane's first (wave_shl:1); lane 63's is the next row's first (row 4 = halo, 8 lanes)
+                const uint32_t after = (r < kUatRows) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p01[(r + 1) % (kUatRows + 1)]) : after_all;
+                uint32_t       p8    = (uint32_t)__builtin_amdgcn_update_dpp((int)after, (int)p01[r], 0x130, 0xF, 0xF, false);
+                if (r == kUatRows && lane == 7) p8 = after_all;
+                const uint32_t byte = sign_byte(p01[r], p23[r], p45[r], p67[r], p8 & 0xFFFFu);
+                if (r < kUatRows || lane < 8) my_bytes[r * 64 + lane] = (uint8_t)byte;
             }
         }
         else
-        { // the stream ends in (or before) this wave's span
-            for (int r = 0; r < kUatRows; r++)
-                sign_bytes[wave * (kUatWaveSamples / 8) + r * 64 + lane] = sign_byte_guarded(iq, lut_s, n, wave_start + (uint64_t)r * kUatRowSamples + (uint64_t)lane * 8);
+        { // the stream ends in (or right after) this span
+            for (int r = 0; r < kUatRows; r++) my_bytes[r * 64 + lane] = sign_byte_guarded(iq, lut_s, n, s0 + (uint64_t)r * kUatRowSamples + (uint64_t)lane * 8);
+            if (lane < 8) my_bytes[kUatRows * 64 + lane] = sign_byte_guarded(iq, lut_s, n, s0 + kUatWaveSamples + (uint64_t)lane * 8);
+            if (fast(span + nwaves)) load(span + nwaves);
         }
-        if (wave == kUatScanWaves - 1)
-        { // halo: the first 64 samples of the next chunk, 8 lanes
-            const uint64_t h0 = base + kUatChunk;
-            uint32_t       byte;
-            if (h0 + 64 + 1 <= n)
-            {
-                uint4 v = {0, 0, 0, 0};
-                if (lane < 8) v = *reinterpret_cast<const uint4*>(iq + h0 + (uint64_t)lane * 8);
-                const uint32_t p01 = lut2(lut_s, v.x), p23 = lut2(lut_s, v.y), p45 = lut2(lut_s, v.z), p67 = lut2(lut_s, v.w);
-                const uint32_t after = lut_s[swz1(iq[h0 + 64])];
-                uint32_t       p8    = (uint32_t)__builtin_amdgcn_update_dpp((int)after, (int)p01, 0x130, 0xF, 0xF, false);
-                if (lane == 7) p8 = after;
-                byte = sign_byte(p01, p23, p45, p67, p8 & 0xFFFFu);
-            }
-            else byte = sign_byte_guarded(iq, lut_s, n, h0 + (uint64_t)(lane & 7) * 8);
-            if (lane < 8) sign_bytes[kUatChunk / 8 + lane] = (uint8_t)byte;
-        }
-    };
-    // ---- B: one word of 32 start positions per lane
-    auto phase_b = [&](uint64_t chunk, int buf)
-    {
-        const uint64_t base = chunk * kUatChunk;
+        wave_lds_fence();
+        // ---- B: one word of 32 start positions per lane
 #if !defined(UAT_EXP_NO_MATCH)
         {
-            const uint32_t w0 = sign_words[buf][tid], w1 = sign_words[buf][tid + 1], w2 = sign_words[buf][tid + 2];
+            const uint32_t w0 = my_words[lane], w1 = my_words[lane + 1], w2 = my_words[lane + 2];
             uint32_t       all = 0xFFFFFFFFu, any = 0u; // over k of "bit k agrees with the ADS-B check word"
 #pragma unroll
             for (int k = 0; k < 18; k++)
             {
                 const int sh = 2 * k;
-                uint32_t  v  = sh == 0 ? w0 : sh < 32 ? __builtin_amdgcn_alignbit(w1, w0, sh) : sh == 32 ? w1 : __builtin_amdgcn_alignbit(w2, w1, sh - 32);
-                if (!((kAdsbSync >> (35 - k)) & 1ull)) v = ~v;
-                all &= v;
-                any |= v;
+                uint32_t  x  = sh == 0 ? w0 : sh < 32 ? __builtin_amdgcn_alignbit(w1, w0, sh) : sh == 32 ? w1 : __builtin_amdgcn_alignbit(w2, w1, sh - 32);
+                if (!((kAdsbSync >> (35 - k)) & 1ull)) x = ~x;
+                all &= x;
+                any |= x;
             }
             uint32_t hits = all | ~any; // ADS-B word: every bit agrees; uplink word: none does
             if (hits)
             {
-                const uint64_t word_start = base + (uint64_t)tid * 32;
+                const uint64_t word_start = s0 + (uint64_t)lane * 32;
                 while (hits)
                 {
                     const int j = __builtin_ctz(hits);
@@ -313,10 +336,10 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
                     if (i + 36 > n) continue;
                     const uint32_t kind  = ((all >> j) & 1u) ? 0u : 1u;
                     const uint32_t value = ((uint32_t)i & 0x7FFFFFFFu) | (kind << 31);
-                    const uint32_t at    = atomicAdd(&parked_count, 1u);
-                    if (at < kUatParkCap) parked[at] = value;
+                    const uint32_t at    = atomicAdd(&parked_count[wave], 1u);
+                    if (at < kUatParkCap) my_parked[at] = value;
                     else
-                    { // more matches in flight than the parking area holds: straight to the global list
+                    { // more matches in one span than the parking area holds: straight to the global list
                         const uint32_t slot = atomicAdd(count, 1u);
                         if (slot < cap) cand[slot] = value;
                     }
@@ -324,29 +347,13 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
             }
         }
 #endif
-    };
-    // Software pipeline, one barrier per chunk: the signs of the next chunk are produced (global loads, LDS gathers) while
-    // the match of the current one runs, from the other sign buffer.
-    uint64_t chunk = blockIdx.x;
-    int      cur   = 0;
-    if (chunk < nchunks) phase_a(chunk, 0);
-    __syncthreads();
-    for (; chunk < nchunks; chunk += gridDim.x, cur ^= 1)
-    {
-        if (chunk + gridDim.x < nchunks) phase_a(chunk + gridDim.x, cur ^ 1);
-        phase_b(chunk, cur);
-        __syncthreads();
-        const uint32_t pending = parked_count < kUatParkCap ? parked_count : kUatParkCap; // same for every lane
-        if (pending >= kUatParkCap / 2 || (pending && chunk + gridDim.x >= nchunks))
-        {
-            if (tid == 0) flush_base = atomicAdd(count, pending);
-            __syncthreads();
-            for (uint32_t k = tid; k < pending; k += kUatScanThreads)
-                if (flush_base + k < cap) cand[flush_base + k] = parked[k];
-            __syncthreads();
-            if (tid == 0) parked_count = 0;
-        }
+        wave_lds_fence();
+        const uint32_t pending = parked_count[wave] < kUatParkCap ? parked_count[wave] : kUatParkCap; // same for every lane
+        if (pending >= kUatParkCap / 2) flush(pending);
     }
+    wave_lds_fence();
+    const uint32_t pending = parked_count[wave] < kUatParkCap ? parked_count[wave] : kUatParkCap;
+    if (pending) flush(pending);
 }
 
 // ---- K3: one wave per candidate: sync re-check, slicing, Reed-Solomon, for the candidate sample and the next one
@@ -718,11 +725,11 @@ hipError_t launch_uat978(const UatArgs& a, hipStream_t stream)
     if (e != hipSuccess) return e;
     if (!a.phases_given)
     {
-        const uint64_t nchunks = (a.nsamples + kUatChunk - 1) / kUatChunk;
+        const uint64_t nwgs = ((a.nsamples + kUatWaveSamples - 1) / kUatWaveSamples + kUatScanWaves - 1) / kUatScanWaves;
 #if !defined(UAT_EXP_GRID)
 #define UAT_EXP_GRID 256
 #endif
-        const uint32_t grid    = (uint32_t)(nchunks < UAT_EXP_GRID ? nchunks : UAT_EXP_GRID);
+        const uint32_t grid = (uint32_t)(nwgs < UAT_EXP_GRID ? nwgs : UAT_EXP_GRID);
         hipLaunchKernelGGL(uat_scan_iq_kernel, dim3(grid), dim3(kUatScanThreads), 0, stream, a.in, a.lut, a.nsamples, a.cand, a.cand_cap, a.counts);
         return hipGetLastError();
     }
