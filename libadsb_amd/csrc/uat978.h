@@ -48,6 +48,7 @@ struct UatArgs
 };
 
 hipError_t launch_uat978(const UatArgs& a, hipStream_t stream);                       // signs + 18-bit match
+hipError_t launch_uat978_order(const uint32_t* cand, uint32_t ncand, uint64_t nsamples, uint32_t* scratch, uint32_t* sorted, hipStream_t stream);
 hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, hipStream_t stream); // one wave per candidate
 hipError_t launch_uat978_rs_selftest(const RsTables* tables, int kind, uint8_t* words, int* results, int count, hipStream_t stream);
 } // namespace adsb_amd

@@ -716,6 +716,71 @@ __global__ __launch_bounds__(64) void uat_demod_kernel(const uint16_t* __restric
         wave_fence(); // raw[] is reused by the next candidate
     }
 }
+// ---- ordering: the matches come out of the search in whatever order the waves flushed them; the host walks them in stream
+// order.  Counting sort by 32 768-sample bin (matches are sparse: ~2^-17 per sample and check word in noise, a handful per
+// bin even in a frame-dense stream), then an insertion sort inside each bin.  Four small launches.
+constexpr uint32_t kUatOrderSpanShift = 15;
+
+__global__ __launch_bounds__(256) void uat_order_count_kernel(const uint32_t* __restrict__ cand, uint32_t ncand, uint32_t* __restrict__ span_count)
+{
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncand; c += gridDim.x * blockDim.x)
+        atomicAdd(&span_count[(cand[c] & 0x7FFFFFFFu) >> kUatOrderSpanShift], 1u);
+}
+
+// exclusive prefix of span_count[0 .. nspans) in place; one workgroup, every lane owns a contiguous slice
+__global__ __launch_bounds__(1024) void uat_order_prefix_kernel(uint32_t* __restrict__ span_count, uint32_t nspans)
+{
+    __shared__ uint32_t partial[1024];
+    const uint32_t      per = (nspans + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < nspans ? lo + per : nspans;
+    uint32_t            sum = 0;
+    for (uint32_t k = lo; k < hi; k++) sum += span_count[k];
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1)
+    { // Hillis-Steele inclusive scan
+        const uint32_t v = threadIdx.x >= d ? partial[threadIdx.x - d] : 0u;
+        __syncthreads();
+        partial[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = partial[threadIdx.x] - sum;
+    for (uint32_t k = lo; k < hi; k++)
+    {
+        const uint32_t c = span_count[k];
+        span_count[k]    = run;
+        run += c;
+    }
+}
+
+// span_offset[] is the exclusive prefix; span_fill[] counts what has been placed (zeroed by the caller)
+__global__ __launch_bounds__(256) void uat_order_scatter_kernel(const uint32_t* __restrict__ cand, uint32_t ncand, const uint32_t* __restrict__ span_offset,
+                                                                uint32_t* __restrict__ span_fill, uint32_t* __restrict__ sorted)
+{
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < ncand; c += gridDim.x * blockDim.x)
+    {
+        const uint32_t v = cand[c], span = (v & 0x7FFFFFFFu) >> kUatOrderSpanShift;
+        sorted[span_offset[span] + atomicAdd(&span_fill[span], 1u)] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void uat_order_within_kernel(const uint32_t* __restrict__ span_offset, const uint32_t* __restrict__ span_fill,
+                                                               uint32_t nspans, uint32_t* __restrict__ sorted)
+{
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nspans; s += gridDim.x * blockDim.x)
+    {
+        const uint32_t n = span_fill[s];
+        if (n < 2) continue;
+        uint32_t* a = sorted + span_offset[s];
+        for (uint32_t i = 1; i < n; i++)
+        { // by sample index; two entries never share one (the check words are complements)
+            const uint32_t v = a[i], key = v & 0x7FFFFFFFu;
+            uint32_t       j = i;
+            for (; j > 0 && (a[j - 1] & 0x7FFFFFFFu) > key; j--) a[j] = a[j - 1];
+            a[j] = v;
+        }
+    }
+}
+
 } // namespace
 
 hipError_t launch_uat978(const UatArgs& a, hipStream_t stream)
@@ -754,6 +819,24 @@ hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, hipStream_t str
     else
         hipLaunchKernelGGL(uat_demod_kernel<false>, dim3(g), dim3(64), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
                            a.uplink_payloads, a.uplink_cap, a.counts + 1);
+    return hipGetLastError();
+}
+
+// cand[0 .. ncand) -> sorted[0 .. ncand) by sample index.  scratch: 2 * nspans words, nspans = spans covering nsamples.
+hipError_t launch_uat978_order(const uint32_t* cand, uint32_t ncand, uint64_t nsamples, uint32_t* scratch, uint32_t* sorted, hipStream_t stream)
+{
+    if (ncand == 0) return hipSuccess;
+    const uint32_t nspans = (uint32_t)((nsamples + (1u << kUatOrderSpanShift) - 1) >> kUatOrderSpanShift);
+    uint32_t*      offset = scratch;
+    uint32_t*      fill   = scratch + nspans;
+    hipError_t     e      = hipMemsetAsync(scratch, 0, 2 * (size_t)nspans * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const uint32_t gc = (ncand + 255) / 256 > 1024 ? 1024 : (ncand + 255) / 256;
+    const uint32_t gs = (nspans + 255) / 256 > 1024 ? 1024 : (nspans + 255) / 256;
+    hipLaunchKernelGGL(uat_order_count_kernel, dim3(gc), dim3(256), 0, stream, cand, ncand, offset);
+    hipLaunchKernelGGL(uat_order_prefix_kernel, dim3(1), dim3(1024), 0, stream, offset, nspans);
+    hipLaunchKernelGGL(uat_order_scatter_kernel, dim3(gc), dim3(256), 0, stream, cand, ncand, offset, fill, sorted);
+    hipLaunchKernelGGL(uat_order_within_kernel, dim3(gs), dim3(256), 0, stream, offset, fill, nspans, sorted);
     return hipGetLastError();
 }
 

@@ -100,7 +100,10 @@ struct adsb_amd_uat
     // scratch sized to the largest stream seen
     uint64_t*  signs_d = nullptr;
     size_t     signs_words = 0;
-    uint32_t*  cand_d = nullptr;
+    uint32_t*  cand_d = nullptr;   // matches as the search flushed them
+    uint32_t*  sorted_d = nullptr; // the same in stream order (+ positions the host asked for, appended)
+    uint32_t*  order_scratch_d = nullptr;
+    size_t     order_scratch_words = 0;
     uint32_t   cand_cap = 0;
     uint32_t*  counts_d = nullptr;
     uint32_t*  counts_h = nullptr; // pinned
@@ -110,8 +113,6 @@ struct adsb_amd_uat
     Pinned<uat_rec_t> recs_h;
     Pinned<uint8_t>   up_h;
     Pinned<uint32_t>  cand_h;
-    std::vector<uint64_t> order_tmp;
-    std::vector<uint64_t> order;                  // main matches: (index << 33 | kind << 32 | record), sorted
     std::unordered_map<uint64_t, uint32_t> extra; // positions asked for on top of those: (index << 1 | kind) -> record
     uint32_t nrecords = 0, nmain = 0, nuplink = 0;
 
@@ -134,7 +135,7 @@ struct adsb_amd_uat
     ~adsb_amd_uat()
     {
         (void)hipSetDevice(device);
-        for (void* p : {(void*)lut_d, (void*)rs_d, (void*)signs_d, (void*)cand_d, (void*)counts_d, (void*)recs_d, (void*)up_d, (void*)in_d,
+        for (void* p : {(void*)lut_d, (void*)rs_d, (void*)signs_d, (void*)cand_d, (void*)sorted_d, (void*)order_scratch_d, (void*)counts_d, (void*)recs_d, (void*)up_d, (void*)in_d,
                         (void*)stage_d, (void*)stage_tmp_d})
             if (p) (void)hipFree(p);
         if (counts_h) (void)hipHostFree(counts_h);
@@ -189,10 +190,19 @@ struct adsb_amd_uat
     int reserve_cand(uint32_t want)
     {
         if (want <= cand_cap) return ADSB_AMD_OK;
+        uint32_t* old_sorted = sorted_d;
         if (cand_d) (void)hipFree(cand_d);
         if (recs_d) (void)hipFree(recs_d);
-        cand_d = nullptr, recs_d = nullptr, cand_cap = 0;
+        cand_d = nullptr, recs_d = nullptr, sorted_d = nullptr;
+        const uint32_t old_cap = cand_cap;
+        cand_cap = 0;
         UAT_HIP(hipMalloc(&cand_d, (size_t)want * sizeof(uint32_t)));
+        UAT_HIP(hipMalloc(&sorted_d, (size_t)want * sizeof(uint32_t)));
+        if (old_sorted)
+        { // the sorted list is the demod kernel's input and grows by the positions the host asks for: keep it
+            UAT_HIP(hipMemcpy(sorted_d, old_sorted, (size_t)std::min(old_cap, want) * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+            (void)hipFree(old_sorted);
+        }
         UAT_HIP(hipMalloc(&recs_d, (size_t)want * sizeof(uat_rec_t)));
         cand_cap = want;
         return ADSB_AMD_OK;
@@ -211,12 +221,12 @@ struct adsb_amd_uat
     {
         UatArgs a{};
         a.in = in, a.lut = lut_d, a.rs_tables = rs_d, a.nsamples = n, a.phases_given = phases_given ? 1 : 0;
-        a.signs = signs_d, a.cand = cand_d, a.cand_cap = cand_cap, a.counts = counts_d;
+        a.signs = signs_d, a.cand = cand_d, a.cand_cap = cand_cap, a.counts = counts_d; // demod_on_device points a.cand at sorted_d
         a.recs = recs_d, a.uplink_payloads = up_d, a.uplink_cap = up_cap;
         return a;
     }
 
-    // GPU part of one process_buffer: afterwards recs_h holds one record per exact 18-bit match and `order` sorts them
+    // GPU part of one process_buffer: afterwards recs_h holds one record per exact 18-bit match, in stream order
     int scan(const uint16_t* in_dev, uint64_t n, bool phases_given)
     {
         if (n >= (1ull << 31)) return fail(ADSB_AMD_EINVAL, "UAT stream longer than 2^31 samples per call");
@@ -225,7 +235,6 @@ struct adsb_amd_uat
         if (rc) return rc;
         nrecords = nmain = nuplink = 0;
         extra.clear();
-        order.clear();
         const double t0 = now_ms();
         for (int attempt = 0;; attempt++)
         {
@@ -246,43 +255,34 @@ struct adsb_amd_uat
             stat_candidates += ncand;
             const double t1 = now_ms();
             rc = reserve_uplink(2 * ncand + 64); // at most two decoded payloads per match
-            if (!rc) rc = demod_on_device(in_dev, n, phases_given, ncand, 0);
+            if (rc) return rc;
+            { // stream order on the device, so that the records arrive in the order the scan loop walks them
+                const size_t words = 2 * (size_t)((n + 32767) / 32768) + 2; // launch_uat978_order: two words per 32 768-sample bin
+                if (words > order_scratch_words)
+                {
+                    if (order_scratch_d) (void)hipFree(order_scratch_d);
+                    order_scratch_d = nullptr, order_scratch_words = 0;
+                    UAT_HIP(hipMalloc(&order_scratch_d, words * sizeof(uint32_t)));
+                    order_scratch_words = words;
+                }
+                UAT_HIP(launch_uat978_order(cand_d, ncand, n, order_scratch_d, sorted_d, stream));
+            }
+            rc = demod_on_device(in_dev, n, phases_given, ncand, 0);
             if (rc) return rc;
             nmain = ncand;
             UAT_HIP(hipEventElapsedTime(&scan_ms, ev[0], ev[1]));
             const double t2 = now_ms();
-            sort_main(ncand);
-            const double t3 = now_ms();
-            wall_ms[0] = (float)(t1 - t0), wall_ms[1] = (float)(t2 - t1), wall_ms[2] = (float)(t3 - t2);
+            wall_ms[0] = (float)(t1 - t0), wall_ms[1] = (float)(t2 - t1), wall_ms[2] = 0.f;
             return ADSB_AMD_OK;
         }
     }
 
-    // order[] = (index << 33 | kind << 32 | record) ascending: LSD radix sort over the 32 key bits that vary (index, kind)
-    void sort_main(uint32_t ncand)
-    {
-        order.resize(ncand);
-        order_tmp.resize(ncand);
-        for (uint32_t k = 0; k < ncand; k++) order[k] = ((uint64_t)recs_h.p[k].index << 33) | ((uint64_t)recs_h.p[k].kind << 32) | k;
-        uint64_t* src = order.data();
-        uint64_t* dst = order_tmp.data();
-        for (int shift = 32; shift < 64; shift += 11)
-        {
-            uint32_t hist[2049] = {0};
-            for (uint32_t k = 0; k < ncand; k++) hist[((src[k] >> shift) & 2047u) + 1]++;
-            for (int b = 0; b < 2048; b++) hist[b + 1] += hist[b];
-            for (uint32_t k = 0; k < ncand; k++) dst[hist[(src[k] >> shift) & 2047u]++] = src[k];
-            std::swap(src, dst);
-        }
-        if (src != order.data()) order.swap(order_tmp);
-    }
-
-    // run K3 over cand_d[first .. first + count) and append the records to recs_h / up_h
+    // run K3 over sorted_d[first .. first + count) and append the records to recs_h / up_h
     int demod_on_device(const uint16_t* in_dev, uint64_t n, bool phases_given, uint32_t count, uint32_t first)
     {
         if (count == 0) return ADSB_AMD_OK;
         UatArgs a = args(in_dev, n, phases_given);
-        a.cand += first;
+        a.cand = sorted_d + first;
         a.recs += first;
         UAT_HIP(recs_h.reserve((size_t)first + count, first));
         UAT_HIP(hipEventRecord(ev[2], stream));
@@ -312,12 +312,15 @@ struct adsb_amd_uat
     // stream (possible only through stale register bits right after a jump)
     int record_for(const uint16_t* in_dev, uint64_t n, bool phases_given, uint32_t index, uint32_t kind, uint32_t* out)
     {
-        const uint64_t key = ((uint64_t)index << 33) | ((uint64_t)kind << 32);
-        auto           it  = std::lower_bound(order.begin(), order.end(), key);
-        if (it != order.end() && (*it >> 32) == (key >> 32))
-        {
-            *out = (uint32_t)*it;
-            return ADSB_AMD_OK;
+        { // the first nmain records are in stream order
+            const uat_rec_t* lo = recs_h.p;
+            const uat_rec_t* hi = recs_h.p + nmain;
+            const uat_rec_t* it = std::lower_bound(lo, hi, index, [](const uat_rec_t& r, uint32_t v) { return r.index < v; });
+            if (it != hi && it->index == index && it->kind == kind)
+            {
+                *out = (uint32_t)(it - lo);
+                return ADSB_AMD_OK;
+            }
         }
         auto ex = extra.find(((uint64_t)index << 1) | kind);
         if (ex != extra.end())
@@ -334,7 +337,7 @@ struct adsb_amd_uat
             (void)keep_up;
         }
         const uint32_t word = (index & 0x7FFFFFFFu) | (kind << 31);
-        UAT_HIP(hipMemcpyAsync(cand_d + nrecords, &word, sizeof(word), hipMemcpyHostToDevice, stream));
+        UAT_HIP(hipMemcpyAsync(sorted_d + nrecords, &word, sizeof(word), hipMemcpyHostToDevice, stream));
         UAT_HIP(hipStreamSynchronize(stream));
         stat_extra++;
         const uint32_t at = nrecords;
@@ -393,7 +396,8 @@ struct adsb_amd_uat
 
         int64_t bit = 0; // next bit the loop will examine
         size_t  pos = 0;
-        auto rec_at  = [&](size_t k) -> const uat_rec_t& { return recs_h.p[(uint32_t)order[k]]; };
+        auto rec_at  = [&](size_t k) -> const uat_rec_t& { return recs_h.p[k]; };
+        const size_t nordered = nmain;
         auto emit = [&](const uat_rec_t& r, const Attempt& a)
         {
             if (cb) cb(user, r.kind ? '+' : '-', a.data, a.len, a.rs, stream_offset + r.index + (uint64_t)a.variant);
@@ -402,14 +406,14 @@ struct adsb_amd_uat
         while (bit < lenbits)
         {
             // --- registers hold only stream bits: the loop fires exactly at the device's matches
-            while (pos < order.size() && (int64_t)(rec_at(pos).index >> 1) + 17 < std::max<int64_t>(bit, kUatCheckBits)) pos++;
-            if (pos >= order.size()) break;
+            while (pos < nordered && (int64_t)(rec_at(pos).index >> 1) + 17 < std::max<int64_t>(bit, kUatCheckBits)) pos++;
+            if (pos >= nordered) break;
             const int64_t startbit = rec_at(pos).index >> 1;
             if (startbit + 17 >= lenbits) break;
             // matches at this start bit: even/odd sample, ADS-B/uplink word
             const uat_rec_t* m[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // [kind][alignment]
             size_t           q       = pos;
-            for (; q < order.size() && (int64_t)(rec_at(q).index >> 1) == startbit; q++)
+            for (; q < nordered && (int64_t)(rec_at(q).index >> 1) == startbit; q++)
             {
                 const uat_rec_t& r     = rec_at(q);
                 m[r.kind][r.index & 1] = &r;
