@@ -139,10 +139,16 @@ namespace ADSB
 {
 std::unique_ptr<IDataProvider> TryCreateADSB1090Handler(std::shared_ptr<TrafficManager> const& trafficManager,
                                                         RTLSDR::IDeviceSelector const* selector, Source sourceId);
+// reference ADSB.h:10-12, 16, 21-23 (definitions UAT978.cpp:114-126, 12-19)
+std::unique_ptr<IDataProvider> TryCreateUAT978Handler(std::shared_ptr<TrafficManager> const& trafficManager,
+                                                      RTLSDR::IDeviceSelector const* selector, Source sourceId);
+TrafficManager**               GetThreadLocalTrafficManager();
 namespace test
 {
 std::unique_ptr<RTLSDR::IDataHandler> TryCreateADSB1090Handler(std::shared_ptr<TrafficManager> const& trafficManager,
                                                                RTLSDR::IDeviceSelector const* selector, Source sourceId);
+std::unique_ptr<RTLSDR::IDataHandler> TryCreateUAT978Handler(std::shared_ptr<TrafficManager> const& trafficManager,
+                                                             RTLSDR::IDeviceSelector const* selector, Source sourceId);
 }
 } // namespace ADSB
 #endif

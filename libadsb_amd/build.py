@@ -16,8 +16,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libadsb_amd.so")
 SYNTH = os.path.join(HERE, "libadsb_synth.so")
 
-HIP_SOURCES = ["scan1090.hip", "uat978.hip", "capi.cpp", "resolver1090.cpp", "adsb1090_gpu_handler.cpp", "uat978_host.cpp"]
-HIP_DEPS = HIP_SOURCES + ["scan1090.h", "uat978.h", "resolver1090.hpp", os.path.join(ROOT, "include", "adsb_amd.h"),
+HIP_SOURCES = ["scan1090.hip", "uat978.hip", "capi.cpp", "resolver1090.cpp", "adsb1090_gpu_handler.cpp", "uat978_host.cpp", "uat978_gpu_handler.cpp"]
+HIP_DEPS = HIP_SOURCES + ["scan1090.h", "uat978.h", "rs978.h", "resolver1090.hpp", os.path.join(ROOT, "include", "adsb_amd.h"),
                            os.path.join(ROOT, "include", "libadsb_iface.hpp")]
 
 
@@ -49,15 +49,17 @@ def build_synth(force=False):
 
 
 CXX_TEST = os.path.join(ROOT, "tests", "cpp", "test_1090_gpu")
+CXX_TEST_978 = os.path.join(ROOT, "tests", "cpp", "test_978_gpu")
 
 
 def build_cxx_test(force=False):
-    """The C++ drop-in test driver (uses the reference-shaped factories exported by libadsb_amd.so)."""
-    src = os.path.join(ROOT, "tests", "cpp", "test_1090_gpu.cpp")
-    if not force and not _stale(CXX_TEST, [src, LIB, os.path.join(ROOT, "include", "libadsb_iface.hpp")]):
-        return CXX_TEST
-    subprocess.check_call(["g++", "-std=c++20", "-O2", "-I" + os.path.join(ROOT, "include"), "-o", CXX_TEST, src,
-                           "-L" + HERE, "-ladsb_amd", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"])
+    """The C++ drop-in test drivers (they use the reference-shaped factories exported by libadsb_amd.so)."""
+    for exe in (CXX_TEST, CXX_TEST_978):
+        src = exe + ".cpp"
+        if not force and not _stale(exe, [src, LIB, os.path.join(ROOT, "include", "libadsb_iface.hpp")]):
+            continue
+        subprocess.check_call(["g++", "-std=c++20", "-O2", "-I" + os.path.join(ROOT, "include"), "-o", exe, src,
+                               "-L" + HERE, "-ladsb_amd", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"])
     return CXX_TEST
 
 

@@ -109,5 +109,7 @@ def test_cxx_factories_are_exported(native_libs):
     # the two factories libadsb's callers bind (reference ADSB.h:13-15, 24-26), same namespaces and signatures
     import subprocess
     syms = subprocess.run(["nm", "-DC", native_libs[0]], capture_output=True, text=True).stdout
+    for name in ("ADSB::TryCreateUAT978Handler", "ADSB::test::TryCreateUAT978Handler", "ADSB::GetThreadLocalTrafficManager"):
+        assert name in syms, name
     assert "ADSB::TryCreateADSB1090Handler(std::shared_ptr<ADSB::TrafficManager> const&, RTLSDR::IDeviceSelector const*, ADSB::Source)" in syms
     assert "ADSB::test::TryCreateADSB1090Handler(std::shared_ptr<ADSB::TrafficManager> const&, RTLSDR::IDeviceSelector const*, ADSB::Source)" in syms

@@ -186,3 +186,21 @@ def test_process_iq_ragged_lengths_around_chunk_and_row_edges(uat):
         got = uat.process_iq(iq)
         assert got == want, n
     assert any(len(O.process_buffer978(lut[base[:2 * n].view(np.uint16)])[0]) > 0 for n in sizes)
+
+
+def test_cxx_drop_in_uat_handler(native_libs, tmp_path):
+    """ADSB::test::TryCreateUAT978Handler -> HandleData -> the host's dump_raw_message (defined by the test binary), with the
+    thread-local traffic manager published as UAT978.cpp:46 does.  Lines == oracle frames, in order."""
+    import subprocess
+    from libadsb_amd import build
+    build.build_cxx_test()
+    iq = synth.fill978(31, 4 * 262144, synth.default_cfg978())
+    path = tmp_path / "978.iq"
+    iq.tofile(path)
+    out = subprocess.run([build.CXX_TEST_978, str(path), "262144"], capture_output=True, timeout=120)
+    assert out.returncode == 0, out.stderr.decode()
+    o = O.Oracle978()
+    want = []
+    for k in range(4):
+        want += ["%s %d %d %s" % (ud, len(p), rs, p.hex()) for ud, p, rs, _ in o.handle_data(iq[k * 262144:(k + 1) * 262144])]
+    assert out.stdout.decode().splitlines() == want and len(want) > 10
