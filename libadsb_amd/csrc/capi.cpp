@@ -140,10 +140,6 @@ int make_args(adsb_amd_ctx* c, const void* iq_device, size_t nbytes, size_t buff
     if (total > 0x7FFFFFFFull) return fail(c, ADSB_AMD_EINVAL, "input too large for one scan call");
     a->total_chunks = (uint32_t)total;
     a->crc_tab      = c->crc_tab;
-    a->stagger      = 1;
-    if (const char* st = std::getenv("ADSB_AMD_STAGGER")) a->stagger = (uint32_t)std::atoi(st); // tuning aid
-    if (const char* tn = std::getenv("ADSB_AMD_TUNE")) a->tune = (uint32_t)std::atoi(tn); // experiment switches
-    if (const char* pl = std::getenv("ADSB_AMD_PHASE_LIMIT")) a->phase_limit = (uint32_t)std::atoi(pl); // profiling aid only
     return ADSB_AMD_OK;
 }
 

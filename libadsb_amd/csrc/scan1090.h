@@ -36,9 +36,6 @@ struct ScanArgs
     adsb_amd_record_t* chunk_records; // total_chunks * cap
     uint32_t*          chunk_counts;  // total_chunks
     uint32_t           cap;           // records per chunk region
-    uint32_t           stagger;       // start offset between the waves of a SIMD, in units of 127*64 clocks (0 = none)
-    uint32_t           tune;          // experiment switches (ADSB_AMD_TUNE), 0 = shipped behaviour
-    uint32_t           phase_limit;   // profiling aid: stop after phase N of a chunk (1 load+s, 2 stage1, 3 stage2); 0 = run everything
 };
 
 inline uint32_t chunks_per_buffer(uint32_t buf_samples)

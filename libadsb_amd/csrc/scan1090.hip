@@ -600,10 +600,9 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
     // demodulation); started together they stay in lockstep and the phases never overlap.  Offsetting each wave by its
     // hardware slot (HW_ID.wave_id, bits 3:0) spreads them over the period so one wave's loads and dependency chains
     // hide under another's arithmetic.  Purely a scheduling hint: results do not depend on it.
-    if (a.stagger)
     {
         const uint32_t wslot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;
-        for (uint32_t k = 0; k < wslot * a.stagger; k++) __builtin_amdgcn_s_sleep(127);
+        for (uint32_t k = 0; k < wslot; k++) __builtin_amdgcn_s_sleep(127);
     }
     // (buffer, chunk-in-buffer) of the current chunk, advanced by the constant stride without dividing in the loop
     const uint32_t step_b = nslot / a.chunks_per_buf, step_c = nslot - step_b * a.chunks_per_buf;
@@ -632,7 +631,6 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         const ChunkGeom cur  = g;
         const uint32_t  me   = chunk;
         const uint32_t  next = chunk + nslot;
-#ifndef ADSB_AMD_NO_PREFETCH
         if (next < end)
         {
             bidx += step_b;
@@ -645,16 +643,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
             g = chunk_geom(a, bidx, cidx);
             load_window(g, lane, raw);
         }
-#endif
         wave_lds_fence();
-#ifndef ADSB_AMD_NO_PREFETCH
-        if (a.phase_limit == 1)
-        {
-            if (next >= end) break;
-            chunk = next;
-            continue;
-        }
-#endif
 
         // ---------------- stage 1 on packed s.  A lane takes 16 consecutive positions (pairs (2i, 2i+1), i = 0..7) of a
         // 1024-position super-row, so the 9-sample look-ahead is amortised over twice as many positions.
@@ -673,20 +662,8 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
             p0[12] = *reinterpret_cast<const uint32_t*>(&tile[w + 24]);
             uint32_t p1[12]; // odd-aligned pairs (s[2i+1], s[2i+2]), funnel-shifted out of p0.  (Reading them from LDS at a 2-byte
                              // offset works on gfx950 but measured 3.7 % slower: misaligned ds_read_b128 is split.)
-#ifndef ADSB_AMD_P1_LDS_UNALIGNED
 #pragma unroll
             for (int i = 0; i < 12; i++) p1[i] = __builtin_amdgcn_alignbit(p0[i + 1], p0[i], 16);
-#else
-            {
-                typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
-                const u32x4_u r0 = *reinterpret_cast<const u32x4_u*>(&tile[w + 1]);
-                const u32x4_u r1 = *reinterpret_cast<const u32x4_u*>(&tile[w + 9]);
-                const u32x4_u r2 = *reinterpret_cast<const u32x4_u*>(&tile[w + 17]);
-                p1[0] = r0.x; p1[1] = r0.y; p1[2] = r0.z; p1[3] = r0.w;
-                p1[4] = r1.x; p1[5] = r1.y; p1[6] = r1.z; p1[7] = r1.w;
-                p1[8] = r2.x; p1[9] = r2.y; p1[10] = r2.z; p1[11] = r2.w;
-            }
-#endif
             uint32_t m2o[10]; // (max(s[2i+1],s[2i+2]), max(s[2i+2],s[2i+3]))
 #pragma unroll
             for (int i = 1; i <= 9; i++) m2o[i] = pk_max(p1[i], p0[i + 1]);
@@ -710,25 +687,6 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
             }
             const uint32_t bits = acc >> 15;
             surv |= (uint64_t)bits << (16 * sr);
-#if defined(ADSB_AMD_PAD_CHEAP) || defined(ADSB_AMD_PAD_PK) || defined(ADSB_AMD_PAD_SALU)
-            { // calibration only: N extra independent instructions of one class per super-row (never in a shipped build)
-                uint32_t t0 = p0[0], t1 = p0[1], t2 = p0[2], t3 = p0[3];
-                uint32_t u0 = (uint32_t)sr;
-#ifdef ADSB_AMD_PAD_CHEAP
-#pragma unroll
-                for (int z = 0; z < ADSB_AMD_PAD_CHEAP / 4; z++) { asm volatile("v_and_b32 %0, %0, %4\n v_and_b32 %1, %1, %4\n v_and_b32 %2, %2, %4\n v_and_b32 %3, %3, %4" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(p0[5])); }
-#endif
-#ifdef ADSB_AMD_PAD_PK
-#pragma unroll
-                for (int z = 0; z < ADSB_AMD_PAD_PK / 4; z++) { asm volatile("v_pk_max_u16 %0, %0, %4\n v_pk_max_u16 %1, %1, %4\n v_pk_max_u16 %2, %2, %4\n v_pk_max_u16 %3, %3, %4" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(p0[5])); }
-#endif
-#ifdef ADSB_AMD_PAD_SALU
-#pragma unroll
-                for (int z = 0; z < ADSB_AMD_PAD_SALU / 4; z++) { asm volatile("s_add_u32 %0, %0, 3\n s_add_u32 %0, %0, 5\n s_add_u32 %0, %0, 7\n s_add_u32 %0, %0, 9" : "+s"(u0) : : "scc"); }
-#endif
-                if ((t0 ^ t1 ^ t2 ^ t3 ^ u0) == 0x12345677u) surv ^= 1; // keep the padding alive
-            }
-#endif
         }
         if (cur.npos < (uint32_t)kChunk)
         { // last chunk of a buffer: positions at or beyond N-240 do not exist (ADSB1090.cpp:772)
@@ -742,15 +700,6 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
             }
         }
 
-#ifndef ADSB_AMD_NO_PREFETCH
-        if (a.phase_limit == 2)
-        {
-            if (lane == 0) a.chunk_counts[me] = (uint32_t)(surv != 0) & 0u;
-            if (next >= end) break;
-            chunk = next;
-            continue;
-        }
-#endif
 
         // ---------------- survivors -> queue -> stage 2 -> demod, at most kQueueCap survivors per pass
         const uint32_t mine = (uint32_t)__builtin_popcountll(surv);
@@ -806,11 +755,10 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
             wave_lds_fence();
 
             // demodulate the candidates, one at a time, whole wave each
-            if (a.phase_limit == 3) n2 = 0;
             for (uint32_t t = 0; t < n2; t++)
             {
                 const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)queue[t]);
-                const int todo = (a.tune & 1u) ? 1 : demod_strong_frame(tile, lane, lt, e, kFront + (int)pos, cur.g0 + pos);
+                const int todo = demod_strong_frame(tile, lane, lt, e, kFront + (int)pos, cur.g0 + pos);
                 if (todo) demod_candidate(tile, lane, lt, e, kFront + (int)pos, cur.g0 + pos, todo == 2);
             }
             wave_lds_fence();
@@ -819,17 +767,6 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
 
         if (next >= end) break;
         chunk = next;
-#ifdef ADSB_AMD_NO_PREFETCH
-        bidx += step_b;
-        cidx += step_c;
-        if (cidx >= a.chunks_per_buf)
-        {
-            cidx -= a.chunks_per_buf;
-            bidx++;
-        }
-        g = chunk_geom(a, bidx, cidx);
-        load_window(g, lane, raw);
-#endif
     }
 }
 

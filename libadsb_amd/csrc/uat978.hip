@@ -169,11 +169,7 @@ __device__ __forceinline__ uint32_t sign_byte(uint32_t p01, uint32_t p23, uint32
 // so samples that differ in Q but not in I pile onto one bank; receiver noise (I, Q within a few LSB of 127) uses ~4 of the
 // 64 banks.  The table is therefore stored with Q's low six bits XORed into those index bits (a bijection), and every
 // look-up applies the same XOR: one extra shift-and-mask and one XOR per two samples.
-#if !defined(UAT_EXP_NO_SWIZZLE)
 __device__ __forceinline__ uint32_t swz2(uint32_t iq2) { return iq2 ^ ((iq2 >> 7) & 0x007E007Eu); } // both u16 halves at once
-#else
-__device__ __forceinline__ uint32_t swz2(uint32_t iq2) { return iq2; }
-#endif
 __device__ __forceinline__ uint32_t swz1(uint32_t iq) { return swz2(iq) & 0xFFFFu; }
 
 // byte offset into the u16 table of the sample in the low / high half of `y`: one SDWA shift each (the compiler would
@@ -193,10 +189,6 @@ __device__ __forceinline__ uint32_t table_offset_hi(uint32_t y)
 
 __device__ __forceinline__ uint32_t lut2(const uint16_t* __restrict__ lut_s, uint32_t iq2)
 { // phases of the two samples in one dword, packed the same way
-#if defined(UAT_EXP_NO_GATHER)
-    (void)lut_s;
-    return iq2 * 0x9E3779B1u;
-#endif
     const uint32_t y  = swz2(iq2);
     const char*    b  = reinterpret_cast<const char*>(lut_s);
     const uint32_t lo = *reinterpret_cast<const uint16_t*>(b + table_offset_lo(y));
@@ -311,7 +303,6 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
         }
         wave_lds_fence();
         // ---- B: one word of 32 start positions per lane
-#if !defined(UAT_EXP_NO_MATCH)
         {
             const uint32_t w0 = my_words[lane], w1 = my_words[lane + 1], w2 = my_words[lane + 2];
             uint32_t       all = 0xFFFFFFFFu, any = 0u; // over k of "bit k agrees with the ADS-B check word"
@@ -346,7 +337,6 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
                 }
             }
         }
-#endif
         wave_lds_fence();
         const uint32_t pending = parked_count[wave] < kUatParkCap ? parked_count[wave] : kUatParkCap; // same for every lane
         if (pending >= kUatParkCap / 2) flush(pending);
@@ -791,10 +781,7 @@ hipError_t launch_uat978(const UatArgs& a, hipStream_t stream)
     if (!a.phases_given)
     {
         const uint64_t nwgs = ((a.nsamples + kUatWaveSamples - 1) / kUatWaveSamples + kUatScanWaves - 1) / kUatScanWaves;
-#if !defined(UAT_EXP_GRID)
-#define UAT_EXP_GRID 256
-#endif
-        const uint32_t grid = (uint32_t)(nwgs < UAT_EXP_GRID ? nwgs : UAT_EXP_GRID);
+        const uint32_t grid = (uint32_t)(nwgs < 256 ? nwgs : 256); // one workgroup per CU (its LDS footprint allows no more)
         hipLaunchKernelGGL(uat_scan_iq_kernel, dim3(grid), dim3(kUatScanThreads), 0, stream, a.in, a.lut, a.nsamples, a.cand, a.cand_cap, a.counts);
         return hipGetLastError();
     }

@@ -1,6 +1,6 @@
 """In-process A/B of kernel variants selected by environment knobs (read per submit): interleaved rounds, median kernel ms.
 
-    python tools/ab.py "ADSB_AMD_TUNE=0" "ADSB_AMD_TUNE=1" ...
+    python tools/ab.py "lib=ab_libs/a.so" "lib=ab_libs/b.so" ...
 """
 import os
 import sys
