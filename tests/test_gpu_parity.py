@@ -7,6 +7,7 @@ from libadsb_amd import synth
 from oracle import oracle_py as O
 
 import helpers as H
+from libadsb_amd.shard import shard_range
 
 pytestmark = pytest.mark.gpu
 BB = A.REF_BUFFER_BYTES
@@ -199,3 +200,31 @@ def test_replay_file_matches_oracle_and_drops_the_partial_buffer(native_libs, tm
     with pytest.raises(A.AdsbAmdError, match="cannot open"):
         h.replay_file(str(tmp_path / "missing.dat"))
     h.close()
+
+
+def test_full_size_1gib_properties_and_sampled_oracle_equality(scanner):
+    """BASELINE configs[1]+[2] at full size: 4096 reference buffers (1 GiB) in one scan.  Size-independent properties
+    (shard invariance, strict order, parity consistency) plus exact equality with the oracle on a random sample of buffers."""
+    nbuf = 4096
+    iq, injected = synth.fill_range(0, nbuf, nthreads=16)
+    full = scanner.scan(iq, BB)
+    parts = []
+    for k in range(8):  # the 8-GPU partition of SURVEY.md 8(e), on one GPU
+        lo, cnt = shard_range(nbuf, k, 8)
+        part = scanner.scan(iq[lo * BB:(lo + cnt) * BB], BB)
+        part["buffer"] += lo
+        parts.append(part)
+    H.assert_records_equal(full, np.concatenate(parts))
+    key = full["buffer"].astype(np.uint64) * (1 << 33) + full["offset"].astype(np.uint64) * 2 + (full["flags"] & 1)
+    assert np.all(np.diff(key.astype(np.int64)) > 0)
+    stateless = full[(full["flags"] & A.F_NEEDS_ICAO) == 0]
+    assert 0.6 * injected < len(stateless) < injected
+    for r in stateless[:: max(1, len(stateless) // 2000)]:
+        msg, nb = bytes(r["msg"]), int(r["nbits"])
+        assert O.lib().oracle1090_checksum(msg, nb) == int.from_bytes(msg[nb // 8 - 3: nb // 8], "big")
+    rng = np.random.default_rng(2024)
+    for b in rng.choice(nbuf, 48, replace=False):
+        want = H.expected_records(iq[b * BB:(b + 1) * BB], BB)
+        got = full[full["buffer"] == b].copy()
+        got["buffer"] = 0
+        H.assert_records_equal(got, want)

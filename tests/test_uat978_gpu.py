@@ -204,3 +204,21 @@ def test_cxx_drop_in_uat_handler(native_libs, tmp_path):
     for k in range(4):
         want += ["%s %d %d %s" % (ud, len(p), rs, p.hex()) for ud, p, rs, _ in o.handle_data(iq[k * 262144:(k + 1) * 262144])]
     assert out.stdout.decode().splitlines() == want and len(want) > 10
+
+
+def test_full_size_1gib_stream_equals_oracle(uat):
+    """BASELINE configs[4] at full size: 512 Mi samples in one process_buffer, device resident, every frame compared."""
+    import torch
+    piece = 64 << 20
+    dev = torch.empty(16 * piece, dtype=torch.uint8, device="cuda")
+    lut = O.phase_lut978()
+    phi = np.empty(8 * piece, dtype=np.uint16)
+    for k in range(16):
+        h = synth.fill978(100 + k, piece, synth.default_cfg978())
+        dev[k * piece:(k + 1) * piece].copy_(torch.from_numpy(h))
+        phi[k * (piece // 2):(k + 1) * (piece // 2)] = lut[h.view(np.uint16)]
+    torch.cuda.synchronize()
+    got = uat.process_device(dev.data_ptr(), dev.numel() // 2)
+    want = O.process_buffer978(phi)
+    assert len(want[0]) > 50000
+    assert got == want
