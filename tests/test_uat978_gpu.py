@@ -222,3 +222,48 @@ def test_full_size_1gib_stream_equals_oracle(uat):
     want = O.process_buffer978(phi)
     assert len(want[0]) > 50000
     assert got == want
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzzed_phase_streams(uat, seed):
+    """Random phase streams salted with sync words at random places and alignments, whole and truncated, clean and with wrong
+    bits, followed by random or valid (and randomly corrupted) frames: exercises false matches, both alignments, the
+    next-sample variant, the else-if rule, failed sync re-checks, Reed-Solomon successes and failures, jumps and the
+    stale-register window right after them."""
+    rng = np.random.default_rng(9780 + seed)
+    step = np.zeros(400000, dtype=np.int64)
+    step[:] = np.where(rng.integers(0, 2, step.size) > 0, 1, -1) * rng.integers(200, 9000, step.size)
+    pos = 3000
+    while pos < step.size - 12000:
+        kind = rng.integers(0, 3)          # 0 short, 1 long, 2 uplink
+        word = U.UPLINK_SYNC if kind == 2 else U.ADSB_SYNC
+        bits = U.bits_of(word, 36)
+        if rng.random() < 0.3:
+            bits = bits[int(rng.integers(1, 4)):]                      # sync word missing its first bits
+        for k in rng.choice(len(bits), int(rng.integers(0, 7)) if rng.random() < 0.4 else 0, replace=False):
+            bits[k] ^= 1                                                # wrong sync bits (up to 6: beyond the tolerance too)
+        if kind == 0:
+            frame = U.short_frame(bytes([0x00]) + rng.integers(0, 256, 17, dtype=np.uint8).tobytes())
+        elif kind == 1:
+            frame = U.long_frame(bytes([int(rng.integers(1, 32)) << 3]) + rng.integers(0, 256, 33, dtype=np.uint8).tobytes())
+        else:
+            frame = U.uplink_frame(rng.integers(0, 256, 432, dtype=np.uint8).tobytes())
+        frame = bytearray(frame)
+        r = rng.random()
+        if r < 0.25:
+            frame = bytearray(rng.integers(0, 256, len(frame), dtype=np.uint8).tobytes())   # not a code word at all
+        elif r < 0.7:
+            for k in rng.choice(len(frame), int(rng.integers(1, 14)), replace=False):
+                frame[k] ^= int(rng.integers(1, 256))
+        bits = bits + U.bytes_to_bits(frame)
+        amp = int(rng.integers(300, 9000))
+        d = np.repeat(np.where(np.array(bits) > 0, amp, -amp), 2) + rng.integers(-amp // 3, amp // 3 + 1, 2 * len(bits))
+        start = pos + int(rng.integers(0, 2))                                               # either sample alignment
+        step[start:start + d.size] = d
+        pos = start + d.size + (0 if rng.random() < 0.3 else int(rng.integers(0, 3000)))      # some frames back to back
+    phi = ((np.cumsum(step) + 12345) & 0xFFFF).astype(np.uint16)
+    want = O.process_buffer978(phi)
+    assert uat.process_phases(phi) == want
+    assert len(want[0]) > 5
+    cut = int(rng.integers(20000, 390000))
+    assert uat.process_phases(phi[:cut]) == O.process_buffer978(phi[:cut])
