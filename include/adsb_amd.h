@@ -161,6 +161,11 @@ void        adsb_amd_handler_set_sample_clock(adsb_amd_handler_t* h, int64_t t0_
  * buffer_bytes as in adsb_amd_scan_1090 (0 = the reference's behaviour: one call, one buffer). */
 long adsb_amd_handler_handle_data(adsb_amd_handler_t* h, const uint8_t* iq_host, size_t nbytes, size_t buffer_bytes,
                                   adsb_amd_on_changed_fn cb, void* user);
+/* Page-locked host memory for the transport's ring slots (RTLSDR.hpp:564-570 keeps BufferCount x BufferLength bytes):
+ * HandleData on a buffer that lives in it uploads by DMA straight from the slot.  Optional; any host pointer works. */
+int  adsb_amd_host_alloc(void** out, size_t nbytes);
+void adsb_amd_host_free(void* p);
+
 /* Recorded-file replay, one pass: what RTLSDR::TestDataReadLoop (RTLSDR.hpp:419-442) feeds a handler -- whole 262144-byte
  * buffers in file order, each demodulated on its own, a trailing partial buffer never delivered -- over buffers
  * [first_buffer, first_buffer + max_buffers) of the file (ranks of a multi-GPU job take disjoint ranges; the resolver state

@@ -30,7 +30,7 @@ EXPORTS = [
     "adsb_amd_scan_1090_submit", "adsb_amd_scan_1090_fetch", "adsb_amd_scan_1090_timing", "adsb_amd_magnitude_1090",
     "adsb_amd_resolver_create", "adsb_amd_resolver_destroy", "adsb_amd_resolver_set_sample_clock", "adsb_amd_resolver_feed",
     "adsb_amd_resolver_aircraft_count", "adsb_amd_handler_create", "adsb_amd_handler_destroy", "adsb_amd_handler_last_error",
-    "adsb_amd_handler_set_sample_clock", "adsb_amd_handler_handle_data", "adsb_amd_handler_replay_file",
+    "adsb_amd_handler_set_sample_clock", "adsb_amd_handler_handle_data", "adsb_amd_handler_replay_file", "adsb_amd_host_alloc", "adsb_amd_host_free",
     "adsb_amd_uat_create", "adsb_amd_uat_destroy", "adsb_amd_uat_last_error", "adsb_amd_uat_handle_data", "adsb_amd_uat_set_carry_full",
     "adsb_amd_uat_stream_state", "adsb_amd_uat_process_phases", "adsb_amd_uat_process_iq", "adsb_amd_uat_timing", "adsb_amd_uat_host_timing", "adsb_amd_uat_phase_lut",
     "adsb_amd_uat_rs_decode", "adsb_amd_uat_rs_decode_device", "adsb_amd_uat_set_dump_raw_message", "init_fec", "process_buffer",
@@ -83,6 +83,8 @@ def lib():
         L.adsb_amd_handler_handle_data.restype = C.c_long
         L.adsb_amd_handler_replay_file.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
         L.adsb_amd_handler_replay_file.restype = C.c_long
+        L.adsb_amd_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        L.adsb_amd_host_free.argtypes = [C.c_void_p]
         L.adsb_amd_uat_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         L.adsb_amd_uat_destroy.argtypes = [C.c_void_p]
         L.adsb_amd_uat_last_error.argtypes = [C.c_void_p]
@@ -253,6 +255,26 @@ class Handler1090:
             raise AdsbAmdError("replay_file failed (%d): %s" % (n, self._l.adsb_amd_handler_last_error(self._h).decode()))
         fr, ac = col.arrays()
         return n, fr, ac
+
+
+class PinnedBuffer:
+    """Page-locked host bytes as a numpy array (adsb_amd_host_alloc): a ring slot HandleData can upload from by DMA."""
+
+    def __init__(self, nbytes):
+        self._l = lib()
+        self._p = C.c_void_p()
+        if self._l.adsb_amd_host_alloc(C.byref(self._p), nbytes) != 0:
+            raise AdsbAmdError("adsb_amd_host_alloc(%d) failed" % nbytes)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self._p.value))
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._l.adsb_amd_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        self.close()
 
 
 UAT_FRAME = C.CFUNCTYPE(None, C.c_void_p, C.c_char, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_uint64)

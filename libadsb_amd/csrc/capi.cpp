@@ -496,6 +496,20 @@ extern "C" long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* 
     return accepted;
 }
 
+// Transport helper: a host that keeps its IQ ring (RTLSDR.hpp:564-570 keeps BufferCount slots of BufferLength bytes) in
+// page-locked memory lets every HandleData upload by DMA straight out of the slot instead of through the runtime's pageable
+// staging path.  The host does not have to link HIP for that.
+extern "C" int adsb_amd_host_alloc(void** out, size_t nbytes)
+{
+    if (!out || nbytes == 0) return ADSB_AMD_EINVAL;
+    *out = nullptr;
+    return hipHostMalloc(out, nbytes, hipHostMallocDefault) == hipSuccess ? ADSB_AMD_OK : ADSB_AMD_EHIP;
+}
+extern "C" void adsb_amd_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 // ------------------------------------------------------------------------------------------------ resolver (host only)
 struct adsb_amd_resolver
 {
