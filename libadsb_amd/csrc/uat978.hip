@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64) void uat_rs_selftest_kernel(const RsTables* __r
 }
 
 template <bool PHASES_GIVEN>
-__global__ __launch_bounds__(64) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
+__global__ __launch_bounds__(64, 8) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
                                                        const RsTables* __restrict__ rs_tables, const uint32_t* __restrict__ cand, uint32_t ncand,
                                                        uat_rec_t* __restrict__ recs, uint8_t* __restrict__ uplink_payloads, uint32_t uplink_cap,
                                                        uint32_t* __restrict__ uplink_count)
