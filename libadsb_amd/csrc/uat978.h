@@ -23,8 +23,9 @@ struct uat_rec_t
     int16_t  rs[2];      // corrected symbols (uplink: sum over the six blocks); 9999 = no frame
     uint32_t slot[2];    // uplink: 432-byte slot of the decoded payload in the side array
     uint32_t pad1;
-    uint64_t window;     // sign bits of samples [2 * (index >> 1), +64): both 18-bit registers at detection time
-    uint64_t after[2];   // sign bits of the 64 samples from bit (index >> 1) + skip + 1 on: [0] short / uplink, [1] long
+    uint64_t window;     // sign bits from sample 2 * (index >> 1) on, low word = even samples (register 0), high word = odd
+                         // samples (register 1), bit k = k-th bit time: both 18-bit registers at detection time
+    uint64_t after[2];   // the same from bit (index >> 1) + skip + 1 on: what enters the registers after the jump; [0] short / uplink, [1] long
     uint8_t  payload[2][34 + 2]; // ADS-B: corrected frame bytes 0..33 (18 of them for a short frame)
 };
 static_assert(sizeof(uat_rec_t) == 128, "record layout");

@@ -362,11 +362,14 @@ __device__ __forceinline__ int dphi_at(const uint16_t* __restrict__ in, const ui
     return phi_difference(a, b);
 }
 
-// sign bits of the 64 samples from p on (bit 0 = sample p; 0 where the difference needs a sample beyond the stream)
+// sign bits of the 64 samples from p on, split by sample alignment the way the two shift registers see them: bit k of the
+// low word = sample p + 2k (register 0 when p is even), bit k of the high word = sample p + 1 + 2k (register 1); 0 where
+// the difference needs a sample beyond the stream
 template <bool PHASES_GIVEN>
 __device__ __forceinline__ uint64_t sign_window(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n, uint64_t p, int lane)
 {
-    return __ballot(dphi_at<PHASES_GIVEN>(in, lut, n, p + (uint64_t)lane) > 0);
+    const uint64_t s = p + 2ull * (uint64_t)(lane & 31) + (uint64_t)(lane >> 5);
+    return __ballot(dphi_at<PHASES_GIVEN>(in, lut, n, s) > 0);
 }
 
 // check_sync_word: centre = mean of the per-class means of dphi over the 36 sync bits (C integer division), then at most

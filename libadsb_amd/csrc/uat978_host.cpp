@@ -48,6 +48,29 @@ const RsTables& rs_tables()
 constexpr uint32_t kCheckMask = (1u << kUatCheckBits) - 1u;
 constexpr uint32_t kCheckAdsb = (uint32_t)(0xEACDDA4E2ull >> 18), kCheckUplink = (uint32_t)(0x153225B1Dull >> 18);
 
+// The scan loop's two 18-bit registers are kept here in stream order: bit k = the k-th oldest of the 18 bits (the reference
+// shifts left, oldest = most significant; the device delivers sign bits LSB-first).
+constexpr uint32_t reverse18(uint32_t x)
+{
+    uint32_t r = 0;
+    for (int k = 0; k < 18; k++) r |= ((x >> k) & 1u) << (17 - k);
+    return r;
+}
+constexpr uint32_t kCheckT[2] = {reverse18(kCheckAdsb), reverse18(kCheckUplink)}; // [0] ADS-B, [1] uplink
+// After a jump a register holds (18 - t) bits from before it and t new ones.  If the old content is itself a check word P
+// (it is, for the register that fired), the old part can only line up with check word X at these t -- a property of the
+// two constants: bit t of kStaleSteps[P][X].  (In fact only P == X, t = 15, 16, 17: the words begin and end with 111 / 000.)
+constexpr uint32_t stale_steps(uint32_t oldw, uint32_t x)
+{
+    uint32_t m = 0;
+    for (int t = 1; t <= 17; t++)
+        if ((oldw >> t) == (x & ((1u << (18 - t)) - 1u))) m |= 1u << t;
+    return m;
+}
+constexpr uint32_t kStaleSteps[2][2] = {{stale_steps(kCheckT[0], kCheckT[0]), stale_steps(kCheckT[0], kCheckT[1])},
+                                        {stale_steps(kCheckT[1], kCheckT[0]), stale_steps(kCheckT[1], kCheckT[1])}};
+constexpr uint32_t kAllSteps = 0x3FFFEu; // t = 1 .. 17
+
 #define UAT_HIP(expr)                                                        \
     do                                                                       \
     {                                                                        \
@@ -379,13 +402,6 @@ struct adsb_amd_uat
         return true;
     }
 
-    static uint32_t reg_from_window(uint64_t window, int alignment)
-    { // 18 sign bits two samples apart, oldest first = most significant
-        uint32_t r = 0;
-        for (int k = 0; k < 18; k++) r = (r << 1) | (uint32_t)((window >> (2 * k + alignment)) & 1u);
-        return r;
-    }
-
     int process(const uint16_t* in_dev, uint64_t len, bool phases_given, uint64_t stream_offset, adsb_amd_uat_frame_fn cb, void* user,
                 int64_t* consumed)
     {
@@ -431,42 +447,51 @@ struct adsb_amd_uat
             emit(*r, a);
             // --- jump: bit = startbit + skip, then the loop's ++.  The registers keep their contents, so for the next 17 bits
             // they mix bits from before the jump with new ones and can fire where the stream itself has no match.
-            uint32_t reg[2]     = {reg_from_window(r->window, 0), reg_from_window(r->window, 1)};
-            uint64_t fresh      = (r->kind || a.skip == kUatShortSkip) ? r->after[0] : r->after[1];
-            bit                 = startbit + a.skip + 1;
-            int64_t mixed_until = bit + 17; // first bit at which both registers hold 18 new bits again
-            int     t           = 0;
-            while (bit < lenbits && bit < mixed_until)
+            uint32_t oldw[2] = {(uint32_t)r->window & kCheckMask, (uint32_t)(r->window >> 32) & kCheckMask};
+            uint64_t fresh   = (r->kind || a.skip == kUatShortSkip) ? r->after[0] : r->after[1];
+            bit              = startbit + a.skip + 1;
+            for (;;)
             {
-                reg[0] = ((reg[0] << 1) | (uint32_t)((fresh >> (2 * t)) & 1u)) & kCheckMask;
-                reg[1] = ((reg[1] << 1) | (uint32_t)((fresh >> (2 * t + 1)) & 1u)) & kCheckMask;
-                t++;
-                uint32_t k2;
-                if (reg[0] == kCheckAdsb || reg[1] == kCheckAdsb) k2 = 0;
-                else if (reg[0] == kCheckUplink || reg[1] == kCheckUplink) k2 = 1;
-                else
+                // steps worth looking at: all 17, unless a register holds a check word (then only where the words overlap themselves)
+                uint32_t steps = 0;
+                for (int g = 0; g < 2; g++)
+                    steps |= oldw[g] == kCheckT[0] ? (kStaleSteps[0][0] | kStaleSteps[0][1])
+                                                   : oldw[g] == kCheckT[1] ? (kStaleSteps[1][0] | kStaleSteps[1][1]) : kAllSteps;
+                const uint32_t newb[2] = {(uint32_t)fresh, (uint32_t)(fresh >> 32)};
+                bool           jumped  = false;
+                while (steps)
                 {
-                    bit++;
-                    continue;
+                    const int t = __builtin_ctz(steps);
+                    steps &= steps - 1;
+                    if (bit + t - 1 >= lenbits) break; // step t examines bit (bit + t - 1)
+                    const uint32_t w0 = ((oldw[0] >> t) | (newb[0] << (18 - t))) & kCheckMask;
+                    const uint32_t w1 = ((oldw[1] >> t) | (newb[1] << (18 - t))) & kCheckMask;
+                    uint32_t       k2;
+                    if (w0 == kCheckT[0] || w1 == kCheckT[0]) k2 = 0;
+                    else if (w0 == kCheckT[1] || w1 == kCheckT[1]) k2 = 1;
+                    else continue;
+                    const int64_t  at_bit = bit + t - 1;
+                    const int64_t  sb2    = at_bit - kUatCheckBits + 1;
+                    const uint32_t index  = (uint32_t)(sb2 * 2 + (w0 == kCheckT[k2] ? 0 : 1));
+                    uint32_t       at     = 0;
+                    rc                    = record_for(in_dev, len, phases_given, index, k2, &at);
+                    if (rc) return rc;
+                    const uat_rec_t& r2 = recs_h.p[at];
+                    Attempt          a2;
+                    if (!attempt(r2, a2)) continue;
+                    emit(r2, a2);
+                    oldw[0] = w0, oldw[1] = w1;
+                    fresh   = (r2.kind || a2.skip == kUatShortSkip) ? r2.after[0] : r2.after[1];
+                    bit     = sb2 + a2.skip + 1;
+                    jumped  = true;
+                    break;
                 }
-                const uint32_t want  = k2 ? kCheckUplink : kCheckAdsb;
-                const int64_t  sb2   = bit - kUatCheckBits + 1;
-                const uint32_t index = (uint32_t)(sb2 * 2 + (reg[0] == want ? 0 : 1));
-                uint32_t       at    = 0;
-                rc                   = record_for(in_dev, len, phases_given, index, k2, &at);
-                if (rc) return rc;
-                const uat_rec_t& r2 = recs_h.p[at];
-                Attempt          a2;
-                if (!attempt(r2, a2))
+                if (!jumped)
                 {
-                    bit++;
-                    continue;
+                    if (bit < lenbits) bit = std::min<int64_t>(bit + 17, lenbits); // both registers hold 18 new bits again from here on;
+                                                                                   // a jump past the end of the scanned part stays where it is
+                    break;
                 }
-                emit(r2, a2);
-                fresh       = (r2.kind || a2.skip == kUatShortSkip) ? r2.after[0] : r2.after[1];
-                bit         = sb2 + a2.skip + 1;
-                mixed_until = bit + 17;
-                t           = 0;
             }
         }
         if (bit < lenbits) bit = lenbits; // no further match: the loop runs to the end
