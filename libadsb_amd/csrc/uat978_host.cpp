@@ -186,7 +186,7 @@ struct adsb_amd_uat
         UAT_HIP(hipMalloc(&rs_d, sizeof(RsTables)));
         UAT_HIP(hipMemcpy(rs_d, &rs_tables(), sizeof(RsTables), hipMemcpyHostToDevice));
         UAT_HIP(hipMalloc(&counts_d, 2 * sizeof(uint32_t)));
-        UAT_HIP(hipHostMalloc(&counts_h, 2 * sizeof(uint32_t)));
+        UAT_HIP(hipHostMalloc(&counts_h, 4 * sizeof(uint32_t))); // [0] matches, [1] uplink slots, [2] one look-up request
         UAT_HIP(hipMalloc(&stage_d, 65536 * sizeof(uint16_t)));
         UAT_HIP(hipMalloc(&stage_tmp_d, 65536 * sizeof(uint16_t)));
         UAT_HIP(hipMemset(stage_d, 0, 65536 * sizeof(uint16_t)));
@@ -359,9 +359,8 @@ struct adsb_amd_uat
             if (rc) return rc;
             (void)keep_up;
         }
-        const uint32_t word = (index & 0x7FFFFFFFu) | (kind << 31);
-        UAT_HIP(hipMemcpyAsync(sorted_d + nrecords, &word, sizeof(word), hipMemcpyHostToDevice, stream));
-        UAT_HIP(hipStreamSynchronize(stream));
+        counts_h[2] = (index & 0x7FFFFFFFu) | (kind << 31); // page-locked: the copy is ordered before the kernel on the stream
+        UAT_HIP(hipMemcpyAsync(sorted_d + nrecords, counts_h + 2, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         stat_extra++;
         const uint32_t at = nrecords;
         int            rc = demod_on_device(in_dev, n, phases_given, 1, at);
