@@ -228,3 +228,46 @@ def test_full_size_1gib_properties_and_sampled_oracle_equality(scanner):
         got = full[full["buffer"] == b].copy()
         got["buffer"] = 0
         H.assert_records_equal(got, want)
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_fuzzed_threshold_cases(scanner, seed):
+    """Buffers built to sit on the slicer's thresholds: samples from a small alphabet (many exact ties), frames whose pulse
+    and gap levels differ by about the 256-magnitude "decided" threshold, strong pulses whose 5/4 phase correction wraps
+    16 bits, pulses with the preceding sample high (out-of-phase preambles), frames back to back and across chunk edges."""
+    rng = np.random.default_rng(1090 + seed)
+    nb, n = 3, BB // 2
+    out = np.empty((nb, n, 2), dtype=np.uint8)
+    alphabet = np.array([[127, 127], [128, 126], [129, 127], [127, 130], [131, 131], [140, 127], [127, 150], [160, 160], [200, 127], [255, 255],
+                         [0, 0], [255, 127], [127, 0], [120, 134]], dtype=np.uint8)
+    for b in range(nb):
+        base = alphabet[rng.integers(0, 5 if seed % 2 else len(alphabet), n)]
+        out[b] = base
+        pos = int(rng.integers(0, 50))
+        while pos < n - 260:
+            hi_level = alphabet[rng.integers(5, len(alphabet))]
+            lo_level = alphabet[rng.integers(0, 6)]
+            if rng.random() < 0.4:  # levels about 256 apart in magnitude: |I-127| differs by ~0.7
+                hi_level = np.array([127 + int(rng.integers(20, 60)), 127], dtype=np.uint8)
+                lo_level = np.array([hi_level[0] - int(rng.integers(0, 3)), 127 + int(rng.integers(0, 2))], dtype=np.uint8)
+            pulses = [0, 2, 7, 9]
+            frame = out[b, pos:pos + 240]
+            frame[:16] = lo_level
+            for k in pulses:
+                frame[k] = hi_level
+            nbits = 112 if rng.random() < 0.6 else 56
+            bits = rng.integers(0, 2, 112)
+            df = int(rng.choice([17, 11, 4, 20, 0, 5, 21, 16, 24, 19, 1]))
+            bits[:5] = [(df >> (4 - k)) & 1 for k in range(5)]
+            for k in range(nbits):
+                first, second = (hi_level, lo_level) if bits[k] else (lo_level, hi_level)
+                if rng.random() < 0.08:
+                    second = first  # a tie inside the frame
+                frame[16 + 2 * k], frame[17 + 2 * k] = first, second
+            if rng.random() < 0.3 and pos > 0:
+                out[b, pos - 1] = hi_level  # energy before the preamble: DetectOutOfPhase
+            pos += int(rng.choice([240, 241, 130, 500, 4096 - 120, 2000]))
+    iq = out.reshape(-1)
+    got = scanner.scan(iq, BB)
+    want = H.expected_records(iq, BB)
+    H.assert_records_equal(got, want)
