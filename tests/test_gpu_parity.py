@@ -271,3 +271,9 @@ def test_fuzzed_threshold_cases(scanner, seed):
     got = scanner.scan(iq, BB)
     want = H.expected_records(iq, BB)
     H.assert_records_equal(got, want)
+    # and through the handler: same accepted frames, aircraft snapshots and callback text as the oracle's sequential loop
+    h = A.Handler1090()
+    fr, ac = h.handle_data(iq, BB)
+    ofr, oac = H.oracle_run(iq, BB)
+    H.assert_streams_equal(fr, ac, ofr, oac)
+    h.close()
