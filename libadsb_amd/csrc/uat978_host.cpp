@@ -353,11 +353,9 @@ struct adsb_amd_uat
         }
         if (nrecords + 1 > cand_cap || nuplink + 2 > up_cap)
         { // replace the device arrays by larger ones (host copies are complete); the slot counter keeps counting
-            const uint32_t keep_up = nuplink;
             int            rc      = reserve_cand(cand_cap * 2 + 64);
             if (!rc) rc = reserve_uplink(up_cap * 2 + 64);
             if (rc) return rc;
-            (void)keep_up;
         }
         counts_h[2] = (index & 0x7FFFFFFFu) | (kind << 31); // page-locked: the copy is ordered before the kernel on the stream
         UAT_HIP(hipMemcpyAsync(sorted_d + nrecords, counts_h + 2, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
