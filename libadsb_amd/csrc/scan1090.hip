@@ -350,7 +350,17 @@ __device__ __forceinline__ int demod_strong_frame(const uint16_t* tile, int lane
     const uint64_t ba      = is_long ? valA : (valA & kMask56);
     const uint64_t bb      = is_long ? valB : 0ull;
     const bool     strong  = is_long ? (strongA == ~0ull && strongB == kMask48) : ((strongA & kMask56) == kMask56);
-    if (!strong || !(is17 || df_is_ap(df))) return 1;
+    if (!strong || !(is17 || df_is_ap(df)))
+    {
+        // Not a strong frame.  Most such candidates are noise that got through the preamble gates; their energy average
+        // (:870-881) is below the gate whichever length the sliced DF bits would select, and the retry does not change that
+        // (the window is restored before the gate, :855-856).  Each |lo-hi| estimate is within 2*kEstErr + 0.5 of the true
+        // integer, so are the averages: 5 below the gate on both is certain.
+        const uint32_t iA = (uint32_t)(fA + 0.5f), iB = has_b ? (uint32_t)(fB + 0.5f) : 0u;
+        const uint32_t e56 = wave_sum(lane < 56 ? iA : 0u), erest = wave_sum((lane >= 56 ? iA : 0u) + iB);
+        if (e56 / 28u + 5u < 2550u && (e56 + erest) / 56u + 5u < 2550u) return 0;
+        return 1;
+    }
     const uint32_t nbits   = is_long ? 112u : 56u;
     const uint32_t tab_a   = is_long ? lt.crc_a : lt.crc_s; // crc_s is 0 on lanes >= 56
     const uint32_t contrib = (((ba >> lane) & 1ull) ? tab_a : 0u) ^ ((has_b && ((bb >> lane) & 1ull)) ? lt.crc_b : 0u);
