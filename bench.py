@@ -75,8 +75,8 @@ def cpu_baseline(iq_host, nbuf_sample, buffer_bytes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps; the clocks and the two-slot pipeline need a few dozen steps to settle (20 steps read ~5 %% slower than 200 or 2000)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mib", type=int, default=1024, help="MiB of u8 IQ per GPU (weak scaling)")
     ap.add_argument("--cpu-buffers", type=int, default=4096, help="reference buffers in the CPU-baseline sample (0: skip)")
     ap.add_argument("--serial", action="store_true", help="submit/fetch one step at a time (no overlap of the record copy with the next "
