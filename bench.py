@@ -286,7 +286,7 @@ def main_uat978(args, rank, local_rank, world, dist, A, synth):
                                    % (npieces * 64),
                        "bytes_per_gpu": int(dev.numel()), "sharding": "replicas only: one independent stream per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "uat_scan_iq_kernel",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic("uat978:%d" % dev.numel()), "kernel": "uat_scan_iq_kernel",
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": int(alg_bytes)},
             "frames_per_step": nframes_all, "demod_kernel_ms": round(demod_ms / args.steps, 4), "matches_per_step_rank0": int(matches),
             "host_wall_ms_last_step": tm["host_wall_ms"],
