@@ -157,3 +157,32 @@ def test_synth_is_deterministic():
     digest = hashlib.sha256(a.tobytes()).hexdigest()
     want = open(os.path.join(ROOT, "tests", "golden", "synth_buffer0.sha256")).read().strip()
     assert digest == want
+
+
+PUBLIC_FRAMES = [  # extended squitters printed in public ADS-B tutorials (e.g. "The 1090 Megahertz Riddle"): independent of the survey
+    "8D4840D6202CC371C32CE0576098", "8D40621D58C382D690C8AC2863A7", "8D40621D58C386435CC412692AD6", "8D485020994409940838175B284F",
+    "8DA05F219B06B6AF189400CBC33F", "8D406B902015A678D4D220AA4BDA", "8D40058B58C901375147EFD09357", "8D40058B58C904A87F402D3B8C59",
+]
+
+
+def test_parity_of_publicly_documented_frames():
+    """The checksum restated from ADSB1090.cpp:266-291 equals the transmitted parity of frames published elsewhere."""
+    for h in PUBLIC_FRAMES:
+        m = bytes.fromhex(h)
+        assert O.lib().oracle1090_checksum(m, 112) == int.from_bytes(m[11:14], "big"), h
+
+
+def test_public_frames_decode_through_the_oracle_and_one_flipped_bit_is_repaired():
+    o = O.Oracle1090()
+    buf = np.full(262144, 127, dtype=np.uint8)
+    for k, h in enumerate(PUBLIC_FRAMES):
+        place(buf, modulate(h), 500 + 3000 * k)
+    damaged = bytearray(bytes.fromhex("8D406B902015A678D4D220AA4BDA"))
+    damaged[6] ^= 0x04  # message bit 53
+    place(buf, modulate(damaged.hex()), 500 + 3000 * len(PUBLIC_FRAMES))
+    fr, ac = o.handle_data(buf)
+    assert [bytes(f["msg"]).hex().upper() for f in fr] == PUBLIC_FRAMES + ["8D406B902015A678D4D220AA4BDA"]
+    assert [int(f["errorbit"]) for f in fr] == [-1] * len(PUBLIC_FRAMES) + [53]
+    assert ac[0]["callsign"].decode().ljust(8) == "KLM1023 " and ac[5]["callsign"].decode().ljust(8) == "EZY85MH "
+    # the classic CPR pair (even then odd, odd is the newer one): 52.26578 N, 3.93891 E
+    assert abs(ac[2]["lat1e7"] - 522657800) < 20 and abs(ac[2]["lon1e7"] - 39389100) < 50 and ac[2]["altitude"] == 38000
