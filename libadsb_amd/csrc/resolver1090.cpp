@@ -225,17 +225,17 @@ long Resolver1090::feed(const adsb_amd_record_t* rec, size_t n, size_t samples_p
         const uint64_t pos = static_cast<uint64_t>(r.buffer) * samples_per_buffer + r.offset;
         const int64_t  t   = now_ns(stream_base_ + pos);
         const bool     ap  = (r.flags & ADSB_AMD_F_NEEDS_ICAO) != 0;
+        Track*         known = nullptr;
         if (ap)
         { // BruteForceAp: the recovered address must have been seen within the TTL (:200-207, :426)
-            auto it = icao_seen_.find(r.addr);
-            if (it == icao_seen_.end() || (t - it->second) > kIcaoTtlNs) continue; // not accepted: the retry record (if any) is next
+            known = table_.find(r.addr);
+            if (!known || !known->seen || (t - known->seen_ns) > kIcaoTtlNs) continue; // not accepted: the retry record (if any) is next
         }
-        else if (r.errorbit == -1) icao_seen_[r.addr] = t; // clean DF11/17 whitelists its address (:590-594)
-
         const ModesFields f = decode_fields(r.msg, r.df, r.nbits, r.errorbit, r.addr);
-        auto              ins = aircraft_.try_emplace(r.addr);
-        Track&            a   = ins.first->second;
-        if (ins.second) a.pub.addr = r.addr;
+        bool              created = false;
+        Track&            a       = known ? *known : table_.get_or_create(r.addr, &created);
+        if (created) a.pub.addr = r.addr;
+        if (!ap && r.errorbit == -1) a.seen = true, a.seen_ns = t; // clean DF11/17 whitelists its address (:590-594)
         apply(f, t, a);
         accepted++;
         next_offset = static_cast<uint64_t>(r.offset) + static_cast<uint64_t>(8 + r.nbits) * 2 + 1; // :931 then the loop's j++
