@@ -39,6 +39,14 @@ def test_create_fails_loudly_without_a_device(native_libs):
         pytest.skip("a GPU is present")
     with pytest.raises(A.AdsbAmdError, match="no usable HIP device"):
         A.Scanner()
+    with pytest.raises(A.AdsbAmdError, match="adsb_amd_handler_create failed"):
+        A.Handler1090()
+    with pytest.raises(A.AdsbAmdError, match="adsb_amd_uat_create failed"):
+        A.Uat978()
+    # argument checks that need no device
+    L = A.lib()
+    assert L.adsb_amd_uat_create(None, 0) == -2 and L.adsb_amd_uat_handle_data(None, None, 0, None, None) == -2
+    assert L.adsb_amd_create(None, 0) == -2 and L.adsb_amd_handler_replay_file(None, b"x", 0, 1, None, None) == -2
     with pytest.raises(A.AdsbAmdError):
         A.Handler1090()
 
