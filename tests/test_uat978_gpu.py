@@ -267,3 +267,46 @@ def test_fuzzed_phase_streams(uat, seed):
     assert len(want[0]) > 5
     cut = int(rng.integers(20000, 390000))
     assert uat.process_phases(phi[:cut]) == O.process_buffer978(phi[:cut])
+
+
+def test_1090_and_978_handlers_run_concurrently_on_one_gpu(native_libs):
+    """libadsb runs the two handlers on two consumer threads (RTLSDR.hpp:470-473).  Each has its own context and streams;
+    interleaved on one GPU they must produce what they produce alone."""
+    import threading
+    import helpers as H
+    BB = A.REF_BUFFER_BYTES
+    iq1090, _ = synth.fill_range(70, 24)
+    iq978 = synth.fill978(41, 24 * BB, synth.default_cfg978())
+    want1090 = H.oracle_run(iq1090, BB)
+    o = O.Oracle978()
+    want978 = []
+    for k in range(24):
+        want978 += o.handle_data(iq978[k * BB:(k + 1) * BB])
+    got = {}
+
+    def run1090():
+        h = A.Handler1090()
+        frames, aircraft = [], []
+        for k in range(24):
+            fr, ac = h.handle_data(iq1090[k * BB:(k + 1) * BB], BB)
+            fr = fr.copy()
+            fr["offset"] += k * (BB // 2)  # frame offsets are relative to the call; the oracle helper numbers them through
+            frames.append(fr), aircraft.append(ac)
+        got["1090"] = (np.concatenate(frames), np.concatenate(aircraft))
+        h.close()
+
+    def run978():
+        u = A.Uat978()
+        out = []
+        for k in range(24):
+            out += u.handle_data(iq978[k * BB:(k + 1) * BB])
+        got["978"] = out
+        u.close()
+
+    threads = [threading.Thread(target=run1090), threading.Thread(target=run978)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    H.assert_streams_equal(got["1090"][0], got["1090"][1], want1090[0], want1090[1])
+    assert got["978"] == want978 and len(want978) > 50
