@@ -740,7 +740,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
             for (uint32_t qb = 0; qb < nq; qb += 64)
             {
                 const uint32_t idx = qb + (uint32_t)lane;
-                bool           ok  = false;
+                bool           ok  = false, unsure = false;
                 uint32_t       pos = 0;
                 if (idx < nq)
                 {
@@ -748,15 +748,41 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
                     // one test on the largest of their s values: m(s) <= high-1  <=>  129600*s <= high^2 - high.
                     pos                 = queue[idx];
                     const int      w    = kFront + (int)pos;
-                    const uint32_t high = (uint32_t)(mag_of_s(tile[w]) + mag_of_s(tile[w + 2]) + mag_of_s(tile[w + 7]) + mag_of_s(tile[w + 9])) / 6u;
                     uint32_t       sq   = tile[w + 4];
                     sq = (tile[w + 5] > sq) ? tile[w + 5] : sq;
                     sq = (tile[w + 11] > sq) ? tile[w + 11] : sq;
                     sq = (tile[w + 12] > sq) ? tile[w + 12] : sq;
                     sq = (tile[w + 13] > sq) ? tile[w + 13] : sq;
                     sq = (tile[w + 14] > sq) ? tile[w + 14] : sq;
-                    const uint32_t se = sq + ((sq + 1u) >> 15);
-                    ok = high != 0 && (uint32_t)__umul24(se, 129600u) <= high * high - high;
+                    const uint32_t s0 = tile[w], s2 = tile[w + 2], s7 = tile[w + 7], s9 = tile[w + 9];
+                    // First on estimates: every magnitude estimate is within kEstErr of the reference's integer, so the sum of
+                    // four is within 4 kEstErr and high = sum / 6 (truncating) lies in [(sum - 5) / 6, sum / 6].
+                    //   surely quiet  : e(max) + kEstErr <= (sum_est - 4 kEstErr - 5) / 6 - 1
+                    //   surely not    : e(max) - kEstErr >= (sum_est + 4 kEstErr) / 6
+                    const float sum_est = 360.0f * (__builtin_amdgcn_sqrtf((float)s0) + __builtin_amdgcn_sqrtf((float)s2) +
+                                                    __builtin_amdgcn_sqrtf((float)s7) + __builtin_amdgcn_sqrtf((float)s9));
+                    const float max_est = mag_estimate(sq);
+                    const bool  quiet   = max_est + kEstErr <= (sum_est - 4.0f * kEstErr - 5.0f) * (1.0f / 6.0f) - 1.0f - 0.01f;
+                    const bool  loud    = max_est - kEstErr >= (sum_est + 4.0f * kEstErr) * (1.0f / 6.0f) + 0.01f;
+                    ok                  = quiet;
+                    unsure              = !(quiet || loud);
+                }
+                if (ballot(unsure))
+                { // some lane is too close to call: the exact test for the whole pass
+                    ok = false;
+                    if (idx < nq)
+                    {
+                        const int      w    = kFront + (int)pos;
+                        const uint32_t high = (uint32_t)(mag_of_s(tile[w]) + mag_of_s(tile[w + 2]) + mag_of_s(tile[w + 7]) + mag_of_s(tile[w + 9])) / 6u;
+                        uint32_t       sq   = tile[w + 4];
+                        sq = (tile[w + 5] > sq) ? tile[w + 5] : sq;
+                        sq = (tile[w + 11] > sq) ? tile[w + 11] : sq;
+                        sq = (tile[w + 12] > sq) ? tile[w + 12] : sq;
+                        sq = (tile[w + 13] > sq) ? tile[w + 13] : sq;
+                        sq = (tile[w + 14] > sq) ? tile[w + 14] : sq;
+                        const uint32_t se = sq + ((sq + 1u) >> 15);
+                        ok = high != 0 && (uint32_t)__umul24(se, 129600u) <= high * high - high;
+                    }
                 }
                 const uint64_t mk = ballot(ok);
                 if (ok) queue[n2 + (uint32_t)__builtin_popcountll(mk & ((1ull << lane) - 1ull))] = (uint16_t)pos;
