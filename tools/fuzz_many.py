@@ -22,3 +22,43 @@ t = time.time()
 for seed in range(100, 100 + n2):
     T2.test_fuzzed_phase_streams(u, seed)
 print("978: %d fuzz seeds identical to the oracle (%.0f s), extra look-ups %d" % (n2, time.time() - t, u.timing()["extra_lookups"]), flush=True)
+
+# generator-driven: random generator settings, random call sizes
+import numpy as np  # noqa: E402
+from libadsb_amd import synth  # noqa: E402
+from oracle import oracle_py as O  # noqa: E402
+import helpers as H  # noqa: E402
+
+n3 = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+rng = np.random.default_rng(7)
+BB = A.REF_BUFFER_BYTES
+t = time.time()
+for k in range(n3):
+    cfg = synth.default_cfg(noise_amp=int(rng.integers(0, 50)), mean_spacing=int(rng.choice([0, 250, 600, 2000, 20000])),
+                            amp_lo=int(rng.integers(5, 100)), amp_hi=int(rng.integers(100, 129)), pct_df17=int(rng.integers(0, 60)),
+                            pct_df11=int(rng.integers(0, 40)), pct_bitflip=int(rng.integers(0, 100)), pct_halfsample=int(rng.integers(0, 100)))
+    iq, _ = synth.fill_range(int(rng.integers(0, 10**6)), 3, cfg=cfg)
+    H.assert_records_equal(sc.scan(iq, BB), H.expected_records(iq, BB))
+    h = A.Handler1090()
+    fr, ac = h.handle_data(iq, BB)
+    ofr, oac = H.oracle_run(iq, BB)
+    H.assert_streams_equal(fr, ac, ofr, oac)
+    h.close()
+print("1090: %d random generator settings identical to the oracle (%.0f s)" % (n3, time.time() - t), flush=True)
+t = time.time()
+for k in range(n3):
+    cfg = synth.default_cfg978(noise_amp=int(rng.integers(0, 30)), amp_lo=int(rng.integers(3, 40)), amp_hi=int(rng.integers(40, 120)),
+                               mean_gap_bits=int(rng.choice([0, 30, 300, 3000, 50000])), pct_uplink=int(rng.integers(0, 100)),
+                               pct_long=int(rng.integers(0, 100)), pct_corrupt=int(rng.integers(0, 100)), max_bad_bytes=int(rng.integers(1, 16)))
+    iq = synth.fill978(int(rng.integers(0, 10**6)), 3 * BB, cfg)
+    full = bool(rng.integers(0, 2))
+    uu, oo = A.Uat978(carry_full=full), O.Oracle978(carry_full=full)
+    pos = 0
+    while pos < iq.size:
+        n = int(rng.choice([BB, BB, 2 * BB, 65536, 30000, 100002]))
+        part = iq[pos:pos + n]
+        assert uu.handle_data(part) == oo.handle_data(part), (k, pos)
+        assert uu.stream_state() == oo.stream_state()
+        pos += n
+    uu.close()
+print("978: %d random generator settings / call sizes identical to the oracle (%.0f s)" % (n3, time.time() - t), flush=True)
