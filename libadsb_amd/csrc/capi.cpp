@@ -35,6 +35,7 @@ struct Slot
     adsb_amd_record_t* regions  = nullptr; // total_chunks * cap
     adsb_amd_record_t* dense    = nullptr;
     uint32_t*          total_d  = nullptr; // device {total, overflow}
+    uint32_t*          work_d   = nullptr; // device: one chunk counter per XCD (scan1090_kernel), zero between scans
     uint32_t*          total_h  = nullptr; // pinned {total, overflow}
     adsb_amd_record_t* host     = nullptr; // pinned result
     size_t             host_cap = 0;       // records
@@ -148,6 +149,7 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     s.args.chunk_records = s.regions;
     s.args.chunk_counts  = s.counts;
     s.args.cap           = (uint32_t)s.cap_per_chunk;
+    s.args.work_counters = s.work_d;
     // Everything on the caller's stream.  (Running the ordering pass on a second stream beside the next scan was
     // measured slower: its workgroups take CU slots from the persistent scan waves and the scan grows a tail.)
     HIP_TRY(c, hipEventRecord(s.ev_begin, s.stream));
@@ -203,6 +205,8 @@ extern "C" int adsb_amd_create(adsb_amd_ctx_t** out, int device)
     for (Slot& s : c->slot)
     {
         if ((e = hipMalloc(&s.total_d, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(total)", e);
+        if ((e = hipMalloc(&s.work_d, 8 * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(work)", e);
+        if ((e = hipMemset(s.work_d, 0, 8 * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(work)", e);
         if ((e = hipHostMalloc(&s.total_h, 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(total)", e);
         if ((e = hipEventCreate(&s.ev_begin)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreate(&s.ev_scan0)) != hipSuccess) return bail("hipEventCreate", e);
@@ -223,6 +227,7 @@ extern "C" void adsb_amd_destroy(adsb_amd_ctx_t* c)
     {
         free_slot(s);
         if (s.total_d) (void)hipFree(s.total_d);
+        if (s.work_d) (void)hipFree(s.work_d);
         if (s.total_h) (void)hipHostFree(s.total_h);
         if (s.host) (void)hipHostFree(s.host);
         if (s.ev_begin) (void)hipEventDestroy(s.ev_begin);

@@ -36,6 +36,7 @@ struct ScanArgs
     adsb_amd_record_t* chunk_records; // total_chunks * cap
     uint32_t*          chunk_counts;  // total_chunks
     uint32_t           cap;           // records per chunk region
+    uint32_t*          work_counters; // one per XCD at [32 * xcd] (own cache line each), zero when the scan starts; the ordering pass zeroes them again
 };
 
 inline uint32_t chunks_per_buffer(uint32_t buf_samples)

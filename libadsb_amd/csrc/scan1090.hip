@@ -614,10 +614,22 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         const uint32_t wslot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;
         for (uint32_t k = 0; k < wslot; k++) __builtin_amdgcn_s_sleep(127);
     }
-    // (buffer, chunk-in-buffer) of the current chunk, advanced by the constant stride without dividing in the loop
-    const uint32_t step_b = nslot / a.chunks_per_buf, step_c = nslot - step_b * a.chunks_per_buf;
-    uint32_t       bidx = chunk / a.chunks_per_buf, cidx = chunk - bidx * a.chunks_per_buf;
-    ChunkGeom      g    = chunk_geom(a, bidx, cidx);
+    // Work distribution inside the XCD's range: the first two chunks of a wave are fixed (slot, slot + nslot), every later
+    // one comes from the XCD's counter.  Chunks differ in cost (candidates to demodulate), and with a fixed stride the
+    // slowest of 4096 waves sets the kernel time; the counter is read two chunks ahead, so its latency never shows.
+    // (One counter per XCD, each on its own 128-byte line, and kGrab chunks per atomic: 131 072 single-chunk atomics on eight
+    // counters sharing one line took 1.1 ms.)
+    constexpr uint32_t kGrab = 4;
+    auto grab = [&]() -> uint32_t
+    {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&a.work_counters[xcd * 32u], kGrab);
+        return first + 2u * nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    uint32_t  next    = chunk + nslot;
+    uint32_t  group   = grab(); // first chunk of the group grabbed last; its chunks are handed out one by one
+    uint32_t  in_group = 0;
+    ChunkGeom g     = chunk_geom(a, chunk / a.chunks_per_buf, chunk % a.chunks_per_buf);
     RawWindow raw;
     load_window(g, lane, raw);
 
@@ -638,19 +650,11 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         if (lane == 0) tile[kFront - 1] = (uint16_t)iq1_to_s(raw.front & 0xFFu, raw.front >> 8);
 
         // ---------------- prefetch: the next chunk's loads fly while this chunk is processed
-        const ChunkGeom cur  = g;
-        const uint32_t  me   = chunk;
-        const uint32_t  next = chunk + nslot;
+        const ChunkGeom cur = g;
+        const uint32_t  me  = chunk;
         if (next < end)
         {
-            bidx += step_b;
-            cidx += step_c;
-            if (cidx >= a.chunks_per_buf)
-            {
-                cidx -= a.chunks_per_buf;
-                bidx++;
-            }
-            g = chunk_geom(a, bidx, cidx);
+            g = chunk_geom(a, next / a.chunks_per_buf, next % a.chunks_per_buf);
             load_window(g, lane, raw);
         }
         wave_lds_fence();
@@ -803,6 +807,12 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
 
         if (next >= end) break;
         chunk = next;
+        next  = group + in_group;
+        if (++in_group == kGrab)
+        {
+            in_group = 0;
+            if (next < end) group = grab();
+        }
     }
 }
 
@@ -834,9 +844,11 @@ __device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t* wa
 
 // block_sums[b] = number of records of chunks [256 b, 256 (b+1)), each chunk clamped to its region size
 __global__ __launch_bounds__(256) void block_sums_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ block_sums,
-                                                         uint32_t nchunks, uint32_t cap, uint32_t* __restrict__ total_overflow)
+                                                         uint32_t nchunks, uint32_t cap, uint32_t* __restrict__ total_overflow,
+                                                         uint32_t* __restrict__ work_counters)
 {
     __shared__ uint32_t wave_tot[4];
+    if (blockIdx.x == 0 && threadIdx.x < 8) work_counters[threadIdx.x * 32u] = 0; // the scan before this pass is done with them; ready for the next
     const uint32_t      c = blockIdx.x * kOrderBlock + threadIdx.x;
     uint32_t            v = (c < nchunks) ? counts[c] : 0u;
     if (v > cap)
@@ -965,7 +977,7 @@ hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_
     if (a.total_chunks == 0) return hipSuccess;
     const uint32_t nblocks = (a.total_chunks + kOrderBlock - 1u) / kOrderBlock;
     hipLaunchKernelGGL(block_sums_kernel, dim3(nblocks), dim3(kOrderBlock), 0, stream, a.chunk_counts, block_sums, a.total_chunks, a.cap,
-                       total_and_overflow);
+                       total_and_overflow, a.work_counters);
     hipLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderBlock), 0, stream, a.chunk_records, a.chunk_counts, block_sums, a.total_chunks,
                        nblocks, a.cap, a.chunks_per_buf, dense, total_and_overflow);
     return hipGetLastError();
