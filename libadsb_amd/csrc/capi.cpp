@@ -205,8 +205,8 @@ extern "C" int adsb_amd_create(adsb_amd_ctx_t** out, int device)
     for (Slot& s : c->slot)
     {
         if ((e = hipMalloc(&s.total_d, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(total)", e);
-        if ((e = hipMalloc(&s.work_d, 8 * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(work)", e);
-        if ((e = hipMemset(s.work_d, 0, 8 * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(work)", e);
+        if ((e = hipMalloc(&s.work_d, 64 * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(work)", e);
+        if ((e = hipMemset(s.work_d, 0, 64 * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(work)", e);
         if ((e = hipHostMalloc(&s.total_h, 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(total)", e);
         if ((e = hipEventCreate(&s.ev_begin)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreate(&s.ev_scan0)) != hipSuccess) return bail("hipEventCreate", e);

@@ -38,6 +38,7 @@ namespace adsb_amd
 namespace
 {
 
+constexpr uint32_t kSubRanges = 4; // work counters per XCD
 constexpr int kQueueCap = 512; // stage-1 survivors processed per pass (a chunk rarely has more than ~60)
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -595,12 +596,16 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
 
     // XCD-aware chunk order: workgroups b and b+8 share an XCD (round-robin dispatch), so give every XCD one
     // contiguous range of chunks and let its workgroups walk that range together -> halo re-reads hit its L2.
+    // Each XCD range is cut into kSubRanges pieces with a work counter each, so that no more than 128 waves share a counter.
     const uint32_t nxcd  = 8;
     const uint32_t xcd   = blockIdx.x % nxcd;
-    const uint32_t slot  = blockIdx.x / nxcd;
-    const uint32_t nslot = gridDim.x / nxcd; // grid is a multiple of 8
-    const uint32_t per   = (a.total_chunks + nxcd - 1) / nxcd;
-    const uint32_t first = xcd * per;
+    const uint32_t wg    = blockIdx.x / nxcd;          // index of this workgroup among those of its XCD
+    const uint32_t sub   = wg % kSubRanges;
+    const uint32_t slot  = wg / kSubRanges;
+    const uint32_t nslot = gridDim.x / (nxcd * kSubRanges); // grid is a multiple of 8 * kSubRanges
+    const uint32_t range = xcd * kSubRanges + sub;
+    const uint32_t per   = (a.total_chunks + nxcd * kSubRanges - 1) / (nxcd * kSubRanges);
+    const uint32_t first = range * per;
     const uint32_t end   = (first + per < a.total_chunks) ? first + per : a.total_chunks;
 
     uint32_t chunk = first + slot;
@@ -614,16 +619,16 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         const uint32_t wslot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;
         for (uint32_t k = 0; k < wslot; k++) __builtin_amdgcn_s_sleep(127);
     }
-    // Work distribution inside the XCD's range: the first two chunks of a wave are fixed (slot, slot + nslot), every later
-    // one comes from the XCD's counter.  Chunks differ in cost (candidates to demodulate), and with a fixed stride the
+    // Work distribution inside a range: the first two chunks of a wave are fixed (slot, slot + nslot), every later one comes
+    // from the range's counter.  Chunks differ in cost (candidates to demodulate), and with a fixed stride the
     // slowest of 4096 waves sets the kernel time; the counter is read two chunks ahead, so its latency never shows.
-    // (One counter per XCD, each on its own 128-byte line, and kGrab chunks per atomic: 131 072 single-chunk atomics on eight
-    // counters sharing one line took 1.1 ms.)
-    constexpr uint32_t kGrab = 4;
+    // (Every counter on its own 128-byte line and at most 128 waves per counter: 131 072 atomics on eight counters that
+    // shared one line took 1.1 ms; on 32 lines they cost nothing measurable.)
+    constexpr uint32_t kGrab = 1;
     auto grab = [&]() -> uint32_t
     {
         uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(&a.work_counters[xcd * 32u], kGrab);
+        if (lane == 0) v = atomicAdd(&a.work_counters[range * 32u], kGrab);
         return first + 2u * nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     };
     uint32_t  next    = chunk + nslot;
@@ -848,7 +853,7 @@ __global__ __launch_bounds__(256) void block_sums_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ work_counters)
 {
     __shared__ uint32_t wave_tot[4];
-    if (blockIdx.x == 0 && threadIdx.x < 8) work_counters[threadIdx.x * 32u] = 0; // the scan before this pass is done with them; ready for the next
+    if (blockIdx.x == 0 && threadIdx.x < 8 * kSubRanges) work_counters[threadIdx.x * 32u] = 0; // the scan before this pass is done with them; ready for the next
     const uint32_t      c = blockIdx.x * kOrderBlock + threadIdx.x;
     uint32_t            v = (c < nchunks) ? counts[c] : 0u;
     if (v > cap)
@@ -967,7 +972,7 @@ hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipS
 #define ADSB_AMD_WAVES_PER_CU 16
 #endif
     uint32_t grid = 256u * ADSB_AMD_WAVES_PER_CU;
-    if (grid > a.total_chunks) grid = ((a.total_chunks + 7u) / 8u) * 8u;
+    if (grid > a.total_chunks) grid = ((a.total_chunks + 8u * kSubRanges - 1u) / (8u * kSubRanges)) * 8u * kSubRanges;
     hipLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
     return hipGetLastError();
 }
