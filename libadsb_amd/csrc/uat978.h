@@ -11,6 +11,7 @@ constexpr int kUatLongBytes   = 48;
 constexpr int kUatShortBytes  = 30;
 constexpr int kUatUplinkBytes = 552;
 constexpr int kUatUplinkBits  = kUatUplinkBytes * 8;
+constexpr uint32_t kUatDemodRanges = 64;
 
 // one per 18-bit match, in candidate order; variant v = frame taken from sample index + v
 struct uat_rec_t
@@ -46,6 +47,7 @@ struct UatArgs
     uat_rec_t*      recs;   // cand_cap entries
     uint8_t*        uplink_payloads; // uplink_cap x 432 bytes
     uint32_t        uplink_cap;
+    uint32_t*       demod_work; // kUatDemodRanges work counters, 32 words apart
 };
 
 hipError_t launch_uat978(const UatArgs& a, hipStream_t stream);                       // signs + 18-bit match

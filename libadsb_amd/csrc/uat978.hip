@@ -588,7 +588,7 @@ template <bool PHASES_GIVEN>
 __global__ __launch_bounds__(64, 8) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
                                                        const RsTables* __restrict__ rs_tables, const uint32_t* __restrict__ cand, uint32_t ncand,
                                                        uat_rec_t* __restrict__ recs, uint8_t* __restrict__ uplink_payloads, uint32_t uplink_cap,
-                                                       uint32_t* __restrict__ uplink_count)
+                                                       uint32_t* __restrict__ uplink_count, uint32_t* __restrict__ work_counters, uint32_t nranges)
 {
     __shared__ RsTables T;
     __shared__ uint8_t  raw[2][kUatUplinkBytes + 8];
@@ -598,8 +598,16 @@ __global__ __launch_bounds__(64, 8) void uat_demod_kernel(const uint16_t* __rest
     for (int i = lane; i < (int)sizeof(RsTables) / 4; i += 64) reinterpret_cast<uint32_t*>(&T)[i] = reinterpret_cast<const uint32_t*>(rs_tables)[i];
     wave_fence();
 
-    for (uint32_t c = blockIdx.x; c < ncand; c += gridDim.x)
+    // Candidates differ a lot in cost (noise that fails the sync re-check, short frames whose long-code attempt has to fail
+    // first, uplink frames with twelve code words), so they are handed out by work counters, not by a fixed stride: the list
+    // is cut into `nranges` pieces, each with a counter on its own cache line; a block takes its first candidate by position.
+    const uint32_t range = blockIdx.x % nranges, slot = blockIdx.x / nranges, nslot = gridDim.x / nranges;
+    const uint32_t per   = (ncand + nranges - 1) / nranges;
+    const uint32_t first = range * per, end = first + per < ncand ? first + per : ncand;
+    for (uint32_t c = first + slot; c < end;)
     {
+        uint32_t grabbed = 0;
+        if (lane == 0) grabbed = atomicAdd(&work_counters[range * 32u], 1u); // used at the end of the trip
         const uint32_t word = cand[c];
         const uint32_t kind = word >> 31;
         const uint64_t idx  = word & 0x7FFFFFFFu;
@@ -707,6 +715,7 @@ __global__ __launch_bounds__(64, 8) void uat_demod_kernel(const uint16_t* __rest
             r->window = w0, r->after[0] = w1, r->after[1] = w2;
         }
         wave_fence(); // raw[] is reused by the next candidate
+        c = first + nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)grabbed);
     }
 }
 // ---- ordering: the matches come out of the search in whatever order the waves flushed them; the host walks them in stream
@@ -802,13 +811,17 @@ hipError_t launch_uat978(const UatArgs& a, hipStream_t stream)
 hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, hipStream_t stream)
 {
     if (ncand == 0) return hipSuccess;
-    uint32_t g = ncand > 8192 ? 8192 : ncand;
+    const uint32_t nranges = ncand >= 4096 ? kUatDemodRanges : 1u;
+    uint32_t       g       = ncand > 8192 ? 8192 : ncand;
+    g                      = ((g + nranges - 1) / nranges) * nranges;
+    hipError_t e = hipMemsetAsync(a.demod_work, 0, kUatDemodRanges * 32 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
     if (a.phases_given)
         hipLaunchKernelGGL(uat_demod_kernel<true>, dim3(g), dim3(64), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
-                           a.uplink_payloads, a.uplink_cap, a.counts + 1);
+                           a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges);
     else
         hipLaunchKernelGGL(uat_demod_kernel<false>, dim3(g), dim3(64), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
-                           a.uplink_payloads, a.uplink_cap, a.counts + 1);
+                           a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges);
     return hipGetLastError();
 }
 

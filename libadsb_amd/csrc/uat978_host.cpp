@@ -129,6 +129,7 @@ struct adsb_amd_uat
     size_t     order_scratch_words = 0;
     uint32_t   cand_cap = 0;
     uint32_t*  counts_d = nullptr;
+    uint32_t*  demod_work_d = nullptr;
     uint32_t*  counts_h = nullptr; // pinned
     uat_rec_t* recs_d = nullptr;
     uint8_t*   up_d = nullptr; // decoded uplink payloads, 432 bytes per slot
@@ -158,7 +159,7 @@ struct adsb_amd_uat
     ~adsb_amd_uat()
     {
         (void)hipSetDevice(device);
-        for (void* p : {(void*)lut_d, (void*)rs_d, (void*)signs_d, (void*)cand_d, (void*)sorted_d, (void*)order_scratch_d, (void*)counts_d, (void*)recs_d, (void*)up_d, (void*)in_d,
+        for (void* p : {(void*)lut_d, (void*)rs_d, (void*)signs_d, (void*)cand_d, (void*)sorted_d, (void*)order_scratch_d, (void*)counts_d, (void*)demod_work_d, (void*)recs_d, (void*)up_d, (void*)in_d,
                         (void*)stage_d, (void*)stage_tmp_d})
             if (p) (void)hipFree(p);
         if (counts_h) (void)hipHostFree(counts_h);
@@ -186,6 +187,7 @@ struct adsb_amd_uat
         UAT_HIP(hipMalloc(&rs_d, sizeof(RsTables)));
         UAT_HIP(hipMemcpy(rs_d, &rs_tables(), sizeof(RsTables), hipMemcpyHostToDevice));
         UAT_HIP(hipMalloc(&counts_d, 2 * sizeof(uint32_t)));
+        UAT_HIP(hipMalloc(&demod_work_d, kUatDemodRanges * 32 * sizeof(uint32_t)));
         UAT_HIP(hipHostMalloc(&counts_h, 4 * sizeof(uint32_t))); // [0] matches, [1] uplink slots, [2] one look-up request
         UAT_HIP(hipMalloc(&stage_d, 65536 * sizeof(uint16_t)));
         UAT_HIP(hipMalloc(&stage_tmp_d, 65536 * sizeof(uint16_t)));
@@ -245,7 +247,7 @@ struct adsb_amd_uat
         UatArgs a{};
         a.in = in, a.lut = lut_d, a.rs_tables = rs_d, a.nsamples = n, a.phases_given = phases_given ? 1 : 0;
         a.signs = signs_d, a.cand = cand_d, a.cand_cap = cand_cap, a.counts = counts_d; // demod_on_device points a.cand at sorted_d
-        a.recs = recs_d, a.uplink_payloads = up_d, a.uplink_cap = up_cap;
+        a.recs = recs_d, a.uplink_payloads = up_d, a.uplink_cap = up_cap, a.demod_work = demod_work_d;
         return a;
     }
 
