@@ -150,8 +150,10 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     s.args.chunk_counts  = s.counts;
     s.args.cap           = (uint32_t)s.cap_per_chunk;
     s.args.work_counters = s.work_d;
-    // Everything on the caller's stream.  (Running the ordering pass on a second stream beside the next scan was
-    // measured slower: its workgroups take CU slots from the persistent scan waves and the scan grows a tail.)
+    // Everything on the caller's stream.  (Running the ordering pass on a second stream beside the next scan was measured
+    // slower, twice: with the fixed-stride scan its workgroups delayed persistent waves and the scan grew a tail; with
+    // the work counters, and even with one wave slot per CU left free, the step went from 0.31 to 0.50 ms -- the small
+    // kernels do not get onto the chip while 4096 persistent workgroups are being placed.)
     HIP_TRY(c, hipEventRecord(s.ev_begin, s.stream));
     HIP_TRY(c, hipEventRecord(s.ev_scan0, s.stream));
     HIP_TRY(c, launch_scan1090(s.args, s.total_d, s.stream));
