@@ -340,13 +340,6 @@ __device__ __forceinline__ int demod_strong_frame(const uint16_t* tile, int lane
     const int      ib    = has_b ? ia + 128 : ia;
     const uint32_t sLoA = tile[ia], sHiA = tile[ia + 1], sLoB = tile[ib], sHiB = tile[ib + 1];
     if (__builtin_amdgcn_readfirstlane((int)(sLoA == sHiA))) return 0; // :839-846, dead on both passes
-    {
-        // Receiver noise that got through the preamble gates: if no sample of the frame reaches s = 51 (magnitude 2571), every
-        // magnitude is at most m(50) = 2546, no |lo - hi| reaches 2550 and the energy gate (:870-881) fails for either length,
-        // on the retry too.  One ballot instead of the estimates below.
-        const uint32_t a = sLoA > sHiA ? sLoA : sHiA, b = sLoB > sHiB ? sLoB : sHiB;
-        if (ballot((a > b ? a : b) > 50u) == 0) return 0;
-    }
     const float    fA = __builtin_fabsf(mag_estimate(sLoA) - mag_estimate(sHiA));
     const float    fB = __builtin_fabsf(mag_estimate(sLoB) - mag_estimate(sHiB));
     const uint64_t strongA = ballot(fA >= 2560.0f), strongB = ballot(has_b && fB >= 2560.0f);

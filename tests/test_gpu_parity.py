@@ -34,6 +34,8 @@ def test_magnitude_all_iq_pairs(scanner):
     dict(amp_lo=100, amp_hi=128, noise_amp=1, pct_halfsample=50),
     dict(pct_bitflip=100, pct_df17=50, pct_df11=50),
     dict(mean_spacing=0, noise_amp=40),
+    dict(noise_amp=0, mean_spacing=600, amp_lo=3, amp_hi=12, pct_halfsample=40),   # frames around the energy gate (mean |lo-hi| 1275)
+    dict(noise_amp=1, mean_spacing=400, amp_lo=5, amp_hi=9, pct_bitflip=30),
 ])
 def test_records_match_oracle(scanner, over):
     cfg = synth.default_cfg(**over)

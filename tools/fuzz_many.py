@@ -37,8 +37,13 @@ for k in range(n3):
     cfg = synth.default_cfg(noise_amp=int(rng.integers(0, 50)), mean_spacing=int(rng.choice([0, 250, 600, 2000, 20000])),
                             amp_lo=int(rng.integers(5, 100)), amp_hi=int(rng.integers(100, 129)), pct_df17=int(rng.integers(0, 60)),
                             pct_df11=int(rng.integers(0, 40)), pct_bitflip=int(rng.integers(0, 100)), pct_halfsample=int(rng.integers(0, 100)))
-    iq, _ = synth.fill_range(int(rng.integers(0, 10**6)), 3, cfg=cfg)
-    H.assert_records_equal(sc.scan(iq, BB), H.expected_records(iq, BB))
+    first = int(rng.integers(0, 10**6))
+    iq, _ = synth.fill_range(first, 3, cfg=cfg)
+    try:
+        H.assert_records_equal(sc.scan(iq, BB), H.expected_records(iq, BB))
+    except AssertionError:
+        print("FAILED at k=%d first_buffer=%d cfg=%s" % (k, first, {f[0]: getattr(cfg, f[0]) for f in cfg._fields_}), flush=True)
+        raise
     h = A.Handler1090()
     fr, ac = h.handle_data(iq, BB)
     ofr, oac = H.oracle_run(iq, BB)
