@@ -249,7 +249,10 @@ def test_fuzzed_threshold_cases(scanner, seed):
         while pos < n - 260:
             hi_level = alphabet[rng.integers(5, len(alphabet))]
             lo_level = alphabet[rng.integers(0, 6)]
-            if rng.random() < 0.4:  # levels about 256 apart in magnitude: |I-127| differs by ~0.7
+            if rng.random() < 0.2:  # around the energy gate: a mean |lo-hi| of 1275 lies between amplitudes 3 (1080) and 4 (1440)
+                hi_level = np.array([127 + int(rng.integers(3, 6)), 127 + int(rng.integers(0, 2))], dtype=np.uint8)
+                lo_level = np.array([127, 127 + int(rng.integers(0, 2))], dtype=np.uint8)
+            elif rng.random() < 0.4:  # levels about 256 apart in magnitude: |I-127| differs by ~0.7
                 hi_level = np.array([127 + int(rng.integers(20, 60)), 127], dtype=np.uint8)
                 lo_level = np.array([hi_level[0] - int(rng.integers(0, 3)), 127 + int(rng.integers(0, 2))], dtype=np.uint8)
             pulses = [0, 2, 7, 9]
