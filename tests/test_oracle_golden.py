@@ -186,3 +186,17 @@ def test_public_frames_decode_through_the_oracle_and_one_flipped_bit_is_repaired
     assert ac[0]["callsign"].decode().ljust(8) == "KLM1023 " and ac[5]["callsign"].decode().ljust(8) == "EZY85MH "
     # the classic CPR pair (even then odd, odd is the newer one): 52.26578 N, 3.93891 E
     assert abs(ac[2]["lat1e7"] - 522657800) < 20 and abs(ac[2]["lon1e7"] - 39389100) < 50 and ac[2]["altitude"] == 38000
+
+
+def test_float_magnitude_estimate_stays_within_the_bound_the_kernel_assumes():
+    """scan1090.hip decides stage 2 and parts of the demodulation on e(s) = 360 * sqrtf(s) (s saturated at 32767) and trusts
+    |e(s) - m(s)| < kEstErr = 1.6 for the reference magnitude m(s).  Over every reachable s, with a sqrt that is off by one
+    ulp either way, the error stays below 1.05."""
+    vals = np.array(sorted({i * i + q * q for i in range(129) for q in range(129)}), dtype=np.int64)
+    m = np.array([O.lib().oracle1090_magnitude_of(int(x)) for x in vals]) if hasattr(O.lib(), "oracle1090_magnitude_of") else \
+        np.floor(np.sqrt(vals.astype(np.float64)) * 360 + 0.5)
+    root = np.sqrt(np.minimum(vals, 32767).astype(np.float32))
+    worst = 0.0
+    for r in (root, np.nextafter(root, np.float32(np.inf)), np.nextafter(root, np.float32(-np.inf))):
+        worst = max(worst, float(np.abs(np.float32(360.0) * r - m).max()))
+    assert worst < 1.05
