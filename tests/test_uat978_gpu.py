@@ -310,3 +310,14 @@ def test_1090_and_978_handlers_run_concurrently_on_one_gpu(native_libs):
         t.join()
     H.assert_streams_equal(got["1090"][0], got["1090"][1], want1090[0], want1090[1])
     assert got["978"] == want978 and len(want978) > 50
+
+
+def test_handle_data_one_large_call(native_libs):
+    """64 MiB through HandleData in one call: 500+ staging rounds of the reference's loop (UAT978.cpp:50-59) on the device."""
+    iq = synth.fill978(55, 64 << 20, synth.default_cfg978())
+    for full in (False, True):
+        u, o = A.Uat978(carry_full=full), O.Oracle978(carry_full=full)
+        got, want = u.handle_data(iq), o.handle_data(iq)
+        assert got == want and len(want) > 3000
+        assert u.stream_state() == o.stream_state()
+        u.close()
