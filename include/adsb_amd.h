@@ -102,7 +102,8 @@ const char* adsb_amd_version(void);
 /* ---------------------------------------------------------------- GPU half */
 typedef struct adsb_amd_ctx adsb_amd_ctx_t;
 
-/* device < 0: current HIP device. */
+/* The demodulating part of ADSB1090Handler (constructed at ADSB1090.cpp:144-154): what HandleData (:158-175) -> DetectModeS
+ * (:741-959) computes from the samples alone.  device < 0: current HIP device. */
 int         adsb_amd_create(adsb_amd_ctx_t** out, int device);
 void        adsb_amd_destroy(adsb_amd_ctx_t* ctx);
 const char* adsb_amd_last_error(const adsb_amd_ctx_t* ctx); /* ctx may be NULL: creation error */
@@ -118,7 +119,8 @@ int adsb_amd_scan_1090(adsb_amd_ctx_t* ctx, const uint8_t* iq_host, size_t nbyte
                        adsb_amd_record_t* out, size_t cap, size_t* n_out);
 
 /*
- * Asynchronous scan of device-resident input.  `slot` (0/1) selects one of two result buffers so
+ * Asynchronous scan of device-resident input (no counterpart in the reference, whose HandleData is synchronous; this is the
+ * recorded-file / batch form of the same DetectModeS work, ADSB1090.cpp:741-881 + :277-332).  `slot` (0/1) selects one of two result buffers so
  * that the device->host copy of one scan overlaps the kernels of the next.  `iq_device` must be
  * 16-byte aligned and stay valid until the matching fetch.  `hip_stream` is a hipStream_t
  * (NULL: the context's own stream).
@@ -134,6 +136,8 @@ int adsb_amd_scan_1090_timing(adsb_amd_ctx_t* ctx, int slot, float* scan_kernel_
 int adsb_amd_magnitude_1090(adsb_amd_ctx_t* ctx, const uint8_t* iq_host, size_t nbytes, uint16_t* mag_out);
 
 /* ---------------------------------------------------------------- host half */
+/* The order-dependent rest of ADSB1090Handler: skip-ahead and retry order (ADSB1090.cpp:886-957), ICAO cache and BruteForceAp
+ * (:195-207, 396-435), DecodeModesMessage (:491-675), UseModesMessage / InteractiveReceiveData / DecodeCpr (:968-1175). */
 typedef struct adsb_amd_resolver adsb_amd_resolver_t;
 
 adsb_amd_resolver_t* adsb_amd_resolver_create(void);
@@ -151,6 +155,7 @@ long adsb_amd_resolver_feed(adsb_amd_resolver_t* r, const adsb_amd_record_t* rec
 size_t adsb_amd_resolver_aircraft_count(const adsb_amd_resolver_t* r);
 
 /* ---------------------------------------------------------------- both: one HandleData-shaped call */
+/* ADSB1090Handler as a whole (ADSB1090.cpp:99-244): create/destroy = ctor/dtor (:144-154), handle_data = HandleData (:158-175). */
 typedef struct adsb_amd_handler adsb_amd_handler_t;
 
 int         adsb_amd_handler_create(adsb_amd_handler_t** out, int device);
