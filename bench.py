@@ -1,37 +1,82 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of the 1090ES IQ -> Mode S record path on MI355X.
 
-One "step" = one pass of the hot path over one batch: every rank demodulates its own shard of
-reference buffers (default 1 GiB = 4096 buffers of 262144 B per GPU, already resident in HBM) and
-brings the sorted candidate records back to the host.  Steps are pipelined over two result slots,
-so the record copy of step k overlaps the kernels of step k+1; the timed region contains K complete
-steps (all records on the host).  No collective is on the data path (independent buffers, SURVEY.md
-section 8e); ranks only agree on the elapsed time (max) and sum their record counts.
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N = 1 (BASELINE configs[1]+[2]): one "step" = one pass of the hot path over one batch: the GPU demodulates 1 GiB of
+synthetic u8 IQ (4096 reference buffers of 262144 B, already resident in HBM) and brings the sorted candidate records
+back to the host.  Steps are pipelined over two result slots (the record copy of step k overlaps the kernels of step
+k+1); the timed region contains K complete steps.  The same JSON line carries the roofline of the dominant kernel, the
+CPU baseline, an "end_to_end" block (records -> callbacks on the host, host-resident input including the upload) and
+the UAT 978 workload (configs[4]) under "uat978".
+
+N > 1 (BASELINE configs[3], the recorded-file case): the recording is N GiB (weak scaling: 1 GiB per GPU), rank r owns
+buffers [r*B/N, (r+1)*B/N) (no halo: buffers are independent; a trailing partial buffer is never
+delivered, reference RTLSDR.hpp:419-442).  One step = every rank scans its shard, the sorted records of all ranks are
+gathered on rank 0 over RCCL (device to device, one fixed-size gather per step) and land in rank 0's host memory as one
+stream in recording order.  Steps are pipelined the same way.  The sequential resolver then runs once over a gathered
+step on rank 0 and is reported beside the rate (resolve_ms): it is host work on one core and not part of `value`.
+
+Started bare with --gpus N > 1 (no RANK in the environment) the script starts its N ranks itself as child processes
+(python -m torch.distributed.run, rendezvous on 127.0.0.1) before anything touches the GPU and exits with their code.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 SETUP_STEPS = 40  # untimed, before the warm-up steps: first-touch of the result regions, clock ramp
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def measured_traffic(bytes_per_gpu):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json:
-    FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc runs of this same workload); None when no matching entry."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps; the clocks and the two-slot pipeline need a few dozen steps to settle (20 steps read ~5 %% slower than 200 or 2000)")
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mib", type=int, default=1024, help="MiB of u8 IQ per GPU (weak scaling)")
+    ap.add_argument("--cpu-buffers", type=int, default=4096, help="reference buffers in the CPU-baseline sample (0: skip)")
+    ap.add_argument("--serial", action="store_true", help="submit/fetch one step at a time (no overlap of the record copy with the next "
+                    "scan); used for rocprofv3 runs, where the runtime's shader-based copy would otherwise co-run with the scan kernel")
+    ap.add_argument("--workload", choices=["1090", "uat978"], default="1090", help="1090: the headline metric (BASELINE configs[1]+[2], and "
+                    "configs[3] when --gpus > 1); uat978: BASELINE configs[4] alone, one independent stream per GPU (replicas only)")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the end_to_end and uat978 blocks (profiling runs)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N > 1 ranks all on cuda:0 with the gloo backend: exercises the "
+                    "multi-rank code path (sharding, record gather, resolve) on a one-GPU box; the numbers mean nothing")
+    ap.add_argument("--dump-stream", default=None, help="N > 1: rank 0 writes the gathered records and the resolved callback stream (frames, "
+                    "aircraft snapshots) of the last step to this .npz file, for the parity test (small --mib only)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """Started bare with --gpus N > 1: start the N ranks as fresh child processes and exit with their return code.  Nothing in
+    this (parent) process has touched the GPU, and it never replaces itself: it waits."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def measured_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/traffic_from_profile.py from the tracked summary: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc runs of this
+    same workload); None when there is no entry for this workload size."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        e = t.get(str(bytes_per_gpu))
+        e = t.get(str(key))
         return int(e["traffic_bytes"]) if e else None
     except Exception:
         return None
@@ -73,26 +118,24 @@ def cpu_baseline(iq_host, nbuf_sample, buffer_bytes):
     return out
 
 
+WORKLOAD_1090 = ("%d MiB synthetic u8 IQ per GPU (%d reference buffers of 262144 B, splitmix64 seed 0x1090AD5B, noise +-3, ~1 frame / 2000 "
+                 "samples), fused magnitude + preamble gates + Manchester slice + phase retry + CRC-24 + 1-bit repair; reference demodulates "
+                 "2 samples/us (2.0 MS/s, SURVEY.md F5)")
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200, help="timed steps; the clocks and the two-slot pipeline need a few dozen steps to settle (20 steps read ~5 %% slower than 200 or 2000)")
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mib", type=int, default=1024, help="MiB of u8 IQ per GPU (weak scaling)")
-    ap.add_argument("--cpu-buffers", type=int, default=4096, help="reference buffers in the CPU-baseline sample (0: skip)")
-    ap.add_argument("--serial", action="store_true", help="submit/fetch one step at a time (no overlap of the record copy with the next "
-                    "scan); used for rocprofv3 runs, where the runtime's shader-based copy would otherwise co-run with the scan kernel")
-    ap.add_argument("--workload", choices=["1090", "uat978"], default="1090", help="1090: the headline metric (BASELINE configs[1]+[2]); "
-                    "uat978: BASELINE configs[4], one independent stream per GPU (the UAT path does not shard: replicas only)")
-    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N > 1 ranks all on cuda:0 with the gloo backend: exercises the "
-                    "multi-rank code path (sharding, barrier, MAX/SUM reductions) on a one-GPU box; the numbers mean nothing")
-    args = ap.parse_args()
+    args = parse_args()
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+
+    import numpy as np  # noqa: F401
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: libadsb_amd has no CPU path")
     if args.rehearse_on_one_gpu:
@@ -111,18 +154,30 @@ def main():
     from libadsb_amd import synth
 
     if args.workload == "uat978":
-        return main_uat978(args, rank, local_rank, world, dist, A, synth)
+        out = bench_uat978(args, rank, local_rank, world, dist, A, synth, torch)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+    elif world == 1:
+        out = bench_1090_single(args, local_rank, A, synth, torch)
+        if not args.no_extras:
+            try:
+                u = bench_uat978(argparse.Namespace(**{**vars(args), "steps": max(5, min(args.steps, 30)), "warmup": min(args.warmup, 3)}),
+                                 0, local_rank, 1, None, A, synth, torch)
+                out["uat978"] = {k: u[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "frames_per_step",
+                                                   "demod_kernel_ms", "matches_per_step_rank0", "host_wall_ms_last_step", "cpu_baseline") if k in u}
+            except Exception as e:  # the headline line must not be lost to the second workload
+                out["uat978"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    else:
+        out = bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
-    BB = A.REF_BUFFER_BYTES
-    nbuf = (args.mib << 20) // BB
-    first = rank * nbuf  # rank r owns buffers [r*nbuf, (r+1)*nbuf) of the recording
-    ncpu = max(1, len(os.sched_getaffinity(0)) // max(1, world))
-    iq_host, injected = synth.fill_range(first, nbuf, nthreads=ncpu)
-    d_iq = torch.from_numpy(iq_host).cuda()
-    torch.cuda.synchronize()
 
-    sc = A.Scanner(local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
+def make_runner(args, sc, d_iq, BB, stream):
     nbytes = d_iq.numel()
 
     def run(steps):
@@ -147,6 +202,20 @@ def main():
         rec = sc.fetch((steps - 1) & 1, copy=False)
         a, b = sc.timing((steps - 1) & 1)
         return rec, k_ms + a, t_ms + b
+    return run
+
+
+def bench_1090_single(args, local_rank, A, synth, torch):
+    BB = A.REF_BUFFER_BYTES
+    nbuf = (args.mib << 20) // BB
+    ncpu = max(1, len(os.sched_getaffinity(0)))
+    iq_host, injected = synth.fill_range(0, nbuf, nthreads=ncpu)
+    d_iq = torch.from_numpy(iq_host).cuda()
+    torch.cuda.synchronize()
+    sc = A.Scanner(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    nbytes = d_iq.numel()
+    run = make_runner(args, sc, d_iq, BB, stream)
 
     # Set-up, not measurement: the first scans fault in the record regions (512 MiB of address space, touched where
     # used) and the clocks ramp up from idle; both are one-off costs of a long-running demodulator.  SETUP_STEPS untimed
@@ -154,99 +223,261 @@ def main():
     run(SETUP_STEPS)
     if args.warmup > 0:
         run(args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rec, k_ms, t_ms = run(args.steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    nrec = int(len(rec))
+    rec = rec.copy()
+
+    samples = nbytes // 2
+    kernel_ms = k_ms / args.steps
+    alg_bytes = 2.0 * samples + 32.0 * nrec
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    # host half on the records of one step: accepted frames -> msgs/s (no listener; with a native counting listener: end_to_end)
+    res = A.Resolver()
+    t1 = time.perf_counter()
+    accepted, _, _ = res.feed(rec, BB // 2, nbuf, collect=False)
+    resolve_s = time.perf_counter() - t1
+    out = {
+        "metric": "Msamples/s demodulated (1090ES u8 IQ -> Mode S frame records)",
+        "value": round(samples * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "setup_steps": SETUP_STEPS, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8 in / u16 integer (bit-exact)", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]+[2]: " + WORKLOAD_1090 % (args.mib, nbuf),
+                   "bytes_per_gpu": nbytes, "buffers_per_gpu": nbuf, "sharding": "one GPU", "pipelined": not args.serial},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(nbytes),
+                     "kernel": "scan1090_kernel", "kernel_ms": round(kernel_ms, 4),
+                     "algorithmic_bytes": int(alg_bytes)},
+        "records_per_step": nrec, "frames_injected": injected,
+        "decoded_msgs_per_step_rank0": int(accepted),
+        # frames through the sequential host half (ICAO cache, decode, CPR, aircraft state): the GPU hands over records for
+        # `accepted` frames per step in ms_per_step, the host resolves them in host_resolve_ms on one core; a pipeline of the
+        # two sustains the slower of the two rates (the host's)
+        "decoded_msgs_per_s": round(min(accepted * args.steps / elapsed, accepted / max(resolve_s, 1e-9)), 1),
+        "decoded_msgs_per_s_gpu_side": round(accepted * args.steps / elapsed, 1),
+        "gpu_enqueue_to_count_ms": round(t_ms / args.steps, 4),
+        "host_resolve_ms_rank0": round(resolve_s * 1e3, 2),
+    }
+    if not args.no_extras:
+        out["end_to_end"] = end_to_end_1090(A, rec, iq_host, BB, nbuf, accepted)
+    if args.cpu_buffers > 0:
+        out["cpu_baseline"] = cpu_baseline(iq_host, min(args.cpu_buffers, nbuf), BB)
+    sc.close()
+    del d_iq
+    torch.cuda.empty_cache()
+    return out
+
+
+def end_to_end_1090(A, rec, iq_host, BB, nbuf, accepted):
+    """What `value` leaves out (it is the device-resident demodulation rate): the host half with a listener attached, and the
+    HandleData-shaped entry point on host memory, upload included.  Same 1 GiB, best of 3."""
+    samples = nbuf * BB // 2
+    out = {}
+    best = 1e9
+    for _ in range(3):
+        r = A.Resolver()
+        t = time.perf_counter()
+        n, _, _ = r.feed(rec, BB // 2, nbuf, collect=False, count_callbacks=True)
+        best = min(best, time.perf_counter() - t)
+        r.close()
+    out["records_to_callbacks_ms"] = round(best * 1e3, 3)
+    out["callbacks"] = int(n)
+    out["callbacks_per_s"] = round(n / best, 1)
+    # HandleData over host memory: upload (pageable, then from page-locked memory) + scan + records to host + resolve + callbacks
+    h = A.Handler1090()
+    h.handle_data(iq_host[:64 * BB], BB, collect=False)
+    best = 1e9
+    for _ in range(3):
+        hh = A.Handler1090()
+        t = time.perf_counter()
+        n2 = hh.handle_data(iq_host, BB, collect=False)
+        best = min(best, time.perf_counter() - t)
+        hh.close()
+    assert n2 == accepted
+    out["handle_data_pageable_1gib_ms"] = round(best * 1e3, 2)
+    out["handle_data_pageable_msamples_per_s"] = round(samples / best / 1e6, 1)
+    try:
+        pin = A.PinnedBuffer(iq_host.size)
+        pin.array[:] = iq_host
+        best = 1e9
+        for _ in range(3):
+            hh = A.Handler1090()
+            t = time.perf_counter()
+            hh.handle_data(pin.array, BB, collect=False)
+            best = min(best, time.perf_counter() - t)
+            hh.close()
+        out["handle_data_pinned_1gib_ms"] = round(best * 1e3, 2)
+        out["handle_data_pinned_msamples_per_s"] = round(samples / best / 1e6, 1)
+        # one live 262144-byte buffer from a page-locked ring slot (the transport's unit, RTLSDR.hpp:55)
+        lat = []
+        for k in range(200):
+            t = time.perf_counter()
+            h.handle_data(pin.array[(k % 64) * BB:(k % 64 + 1) * BB], 0, collect=False)
+            lat.append(time.perf_counter() - t)
+        lat.sort()
+        out["live_buffer_ms_median"] = round(lat[len(lat) // 2] * 1e3, 4)
+        out["live_buffer_ms_p99"] = round(lat[int(len(lat) * 0.99)] * 1e3, 4)
+        pin.close()
+    except Exception as e:
+        out["pinned_error"] = repr(e)
+    h.close()
+    return out
+
+
+def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
+    """BASELINE configs[3]: the recording is world x args.mib, rank r scans buffers [r*B/N, (r+1)*B/N), records gathered on rank 0."""
+    import numpy as np
+    from libadsb_amd.shard import RootGather, shard_range
+    BB = A.REF_BUFFER_BYTES
+    nbuf_total = world * ((args.mib << 20) // BB)
+    first, nbuf = shard_range(nbuf_total, rank, world)
+    ncpu = max(1, len(os.sched_getaffinity(0)) // world)
+    iq_host, injected = synth.fill_range(first, nbuf, nthreads=ncpu)
+    d_iq = torch.from_numpy(iq_host).cuda()
+    torch.cuda.synchronize()
+    sc = A.Scanner(local_rank)
+    compute = torch.cuda.current_stream()
+    comm = torch.cuda.Stream()
+    nbytes = d_iq.numel()
+    on_device = dist.get_backend() == "nccl"
+
+    # size the fixed gather buffers from a first scan (+25 % and the same on every rank)
+    sc.submit(d_iq.data_ptr(), nbytes, BB, compute.cuda_stream, 0)
+    n0 = len(sc.fetch(0, copy=False))
+    capt = torch.tensor([n0 + n0 // 4 + 4096], dtype=torch.int64, device="cuda" if on_device else "cpu")
+    dist.all_reduce(capt, op=dist.ReduceOp.MAX)
+    cap = int(capt.item())
+    rg = RootGather(cap)
+
+    def deliver(slot):
+        """Records of `slot` -> rank 0 (collective).  Device path: scanner -> send buffer (device to device, on the side stream) ->
+        RCCL gather -> rank 0's page-locked host memory; the compute stream only waits for the first of those copies."""
+        if on_device:
+            with torch.cuda.stream(comm):
+                n = sc.fetch_device(slot, rg.records_ptr(), cap, comm.cuda_stream)
+                ev = comm.record_event()
+                compute.wait_event(ev)  # the slot's device array may be overwritten by the next scan once it has been copied
+                return rg.gather(n, first)
+        rec = sc.fetch(slot, copy=False)
+        rg.host_records_view()[:len(rec)] = rec
+        return rg.gather(len(rec), first)
+
+    def run(steps):
+        k_ms = 0.0
+        out = None
+        sc.submit(d_iq.data_ptr(), nbytes, BB, compute.cuda_stream, 0)
+        for i in range(1, steps):
+            sc.submit(d_iq.data_ptr(), nbytes, BB, compute.cuda_stream, i & 1)
+            out = deliver((i - 1) & 1)
+            k_ms += sc.timing((i - 1) & 1)[0]
+        out = deliver((steps - 1) & 1)
+        return out, k_ms + sc.timing((steps - 1) & 1)[0]
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
+    run(SETUP_STEPS if not args.rehearse_on_one_gpu else 2)
+    if args.warmup > 0:
+        run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    rec, k_ms, t_ms = run(args.steps)
+    rec, k_ms = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
 
-    nrec = int(len(rec))
-    rec = rec.copy()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([nrec, injected], dtype=torch.int64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        nrec_all, injected_all = int(c[0].item()), int(c[1].item())
-    else:
-        nrec_all, injected_all = nrec, injected
+    # serial breakdown of one step (untimed region): scan, then gather, nothing overlapped
+    barrier()
+    ts = time.perf_counter()
+    sc.submit(d_iq.data_ptr(), nbytes, BB, compute.cuda_stream, 0)
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
+    rec = deliver(0)
+    torch.cuda.synchronize()
+    te = time.perf_counter()
+    # the round-1 definition for comparison: independent shards, records to each rank's own host, no gather
+    run1 = make_runner(args, sc, d_iq, BB, compute.cuda_stream)
+    run1(5)
+    barrier()
+    t1 = time.perf_counter()
+    run1(args.steps)
+    barrier()
+    indep = time.perf_counter() - t1
 
+    dev = "cuda" if on_device else "cpu"
+    t = torch.tensor([elapsed, indep, tg - ts, te - tg], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, indep, scan_serial, gather_serial = [float(x) for x in t.tolist()]
+    c = torch.tensor([injected, k_ms / args.steps * 1e3], dtype=torch.float64, device=dev)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    injected_all, kernel_us_sum = int(c[0].item()), float(c[1].item())
+    out = None
     if rank == 0:
-        samples_rank = nbytes // 2
-        samples_all = samples_rank * world
-        value = samples_all * args.steps / elapsed / 1e6
-        kernel_ms = k_ms / args.steps
-        alg_bytes = 2.0 * samples_rank + 32.0 * nrec
+        samples_all = nbuf_total * BB // 2
+        kernel_ms = kernel_us_sum / 1e3 / world  # mean over ranks of the scan kernel's launch duration
+        nrec = len(rec)
+        alg_bytes = 2.0 * (samples_all / world) + 32.0 * (nrec / world)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        # host half on the records of one step (rank 0's shard): accepted frames -> msgs/s
         res = A.Resolver()
         t1 = time.perf_counter()
-        accepted, _, _ = res.feed(rec, BB // 2, nbuf, collect=False)
+        accepted, fr, ac = res.feed(rec, BB // 2, nbuf_total, collect=bool(args.dump_stream))
         resolve_s = time.perf_counter() - t1
+        if args.dump_stream:
+            np.savez(args.dump_stream, records=rec, frames=fr, aircraft=ac, nbuf_total=nbuf_total)
         out = {
             "metric": "Msamples/s demodulated (1090ES u8 IQ -> Mode S frame records)",
-            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "setup_steps": SETUP_STEPS, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8 in / u16 integer (bit-exact)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]+[2]: %d MiB synthetic u8 IQ per GPU (%d reference buffers of 262144 B, splitmix64 seed "
-                                   "0x1090AD5B, noise +-3, ~1 frame / 2000 samples), fused magnitude + preamble gates + Manchester slice + "
-                                   "phase retry + CRC-24 + 1-bit repair; reference demodulates 2 samples/us (2.0 MS/s, SURVEY.md F5)"
-                                   % (args.mib, nbuf),
-                       "bytes_per_gpu": nbytes, "buffers_per_gpu": nbuf, "sharding": "contiguous buffer ranges, no data-path collective",
-                       "pipelined": not args.serial},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(nbytes),
-                         "kernel": "scan1090_kernel", "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes": int(alg_bytes)},
-            "records_per_step": nrec_all, "frames_injected": injected_all,
-            "decoded_msgs_per_step_rank0": int(accepted),
-            # frames through the sequential host half (ICAO cache, decode, CPR, aircraft state): the GPU hands over records for
-            # `accepted` frames per step in ms_per_step, the host resolves them in host_resolve_ms on one core; a pipeline of the
-            # two sustains the slower of the two rates (the host's)
-            "decoded_msgs_per_s": round(min(accepted * world * args.steps / elapsed, accepted * world / max(resolve_s, 1e-9)), 1),
-            "decoded_msgs_per_s_gpu_side": round(accepted * world * args.steps / elapsed, 1),
-            "gpu_enqueue_to_count_ms": round(t_ms / args.steps, 4),
-            "host_resolve_ms_rank0": round(resolve_s * 1e3, 2),
+            "value": round(samples_all * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "setup_steps": SETUP_STEPS, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8 in / u16 integer (bit-exact)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: recorded-file case, %d MiB recording = " % (world * args.mib) + WORKLOAD_1090 % (args.mib, nbuf)
+                                   + "; rank r scans buffers [r*B/N, (r+1)*B/N), sorted records of all ranks gathered on rank 0 (%s, one "
+                                     "fixed-size gather per step, device to device) and copied to its host memory in recording order"
+                                   % ("RCCL over xGMI" if on_device else "gloo: REHEARSAL on one GPU, numbers meaningless"),
+                       "bytes_per_gpu": nbytes, "buffers_per_gpu": nbuf, "buffers_total": nbuf_total,
+                       "sharding": "contiguous buffer ranges, no halo, no collective on the sample path; one record gather per step", "pipelined": True},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": measured_traffic(nbytes), "kernel": "scan1090_kernel", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes": int(alg_bytes), "note": "per GPU, mean over ranks"},
+            "records_per_step": nrec, "frames_injected": injected_all, "decoded_msgs_per_step": int(accepted),
+            "serial_step_ms": {"scan_and_order": round(scan_serial * 1e3, 4), "gather_to_rank0_host": round(gather_serial * 1e3, 4)},
+            "resolve_ms_rank0": round(resolve_s * 1e3, 2),
+            "independent_shards_value": round(samples_all * args.steps / indep / 1e6, 1),
+            "gather_bytes_per_step": int(nrec * 32),
         }
-        if world == 1 and args.cpu_buffers > 0:
-            out["cpu_baseline"] = cpu_baseline(iq_host, min(args.cpu_buffers, nbuf), BB)
-        print(json.dumps(out), flush=True)
     sc.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
 
 
-def main_uat978(args, rank, local_rank, world, dist, A, synth):
+def bench_uat978(args, rank, local_rank, world, dist, A, synth, torch):
     """BASELINE configs[4]: UAT 978 u8 IQ (the reference's UAT input is u8, not i16) -> frames.  A step is one
     process_buffer over the rank's whole device-resident stream: discriminator + sync search, sync re-check + slicing +
     Reed-Solomon per match, records to the host, the host scan loop (no up-calls).  Streams are independent replicas."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
     piece = 64 << 20
     npieces = max(1, (args.mib << 20) // piece)
     cfg = synth.default_cfg978()
     dev = torch.empty(npieces * piece, dtype=torch.uint8, device="cuda")
+    nthreads = max(1, min(npieces, len(os.sched_getaffinity(0)) // max(1, world), 16))
     first = None
-    for k in range(npieces):
-        h = synth.fill978(rank * npieces + k, piece, cfg)
-        first = h if first is None else first
-        dev[k * piece:(k + 1) * piece].copy_(torch.from_numpy(h))
+    with ThreadPoolExecutor(nthreads) as ex:  # the generator releases the GIL (ctypes)
+        for k0 in range(0, npieces, nthreads):
+            ks = list(range(k0, min(npieces, k0 + nthreads)))
+            for k, h in zip(ks, ex.map(lambda k: synth.fill978(rank * npieces + k, piece, cfg), ks)):
+                first = h if first is None else first
+                dev[k * piece:(k + 1) * piece].copy_(torch.from_numpy(h))
     torch.cuda.synchronize()
     nsamples = dev.numel() // 2
     u = A.Uat978(local_rank)
 
     def run(steps):
         scan = demod = 0.0
-        frames = 0
         for _ in range(steps):
-            out, _ = u.process_device(dev.data_ptr(), nsamples, collect=False)
+            u.process_device(dev.data_ptr(), nsamples, collect=False)
             tm = u.timing()
             scan += tm["scan_ms"]
             demod += tm["demod_ms"]
@@ -279,30 +510,36 @@ def main_uat978(args, rank, local_rank, world, dist, A, synth):
         nframes_all = int(c.item())
     else:
         nframes_all = nframes
+    out = None
     if rank == 0:
-        kernel_ms = scan_ms / args.steps
-        alg_bytes = 2.0 * nsamples
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        scan_k, demod_k = scan_ms / args.steps, demod_ms / args.steps
         tm = u.timing()
+        # the dominant kernel by time is reported in "roofline"; the other one beside it
+        alg_bytes = 2.0 * nsamples
+        scan_roof = {"bound": "hbm", "achieved": round(alg_bytes / (scan_k * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg_bytes / (scan_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": measured_traffic("uat978:%d" % dev.numel()),
+                     "kernel": "uat_scan_iq_kernel", "kernel_ms": round(scan_k, 4), "algorithmic_bytes": int(alg_bytes)}
         out = {
             "metric": "Msamples/s demodulated (UAT 978 u8 IQ -> Reed-Solomon-corrected frames)",
             "value": round(nsamples * world * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8 in / u16 phase, GF(256) (bit-exact vs oracle)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8 in / u16 phase, GF(256) (bit-exact vs oracle; parity unpinned: dump978 is un-vendored)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: %d MiB synthetic UAT 978 u8 IQ per GPU (CPFSK h=0.6, 2 samples/bit, seed 0x978AD5B), "
                                    "phase LUT + discriminator + 18-bit sync search + 36-bit sync re-check + slicing + RS(30,18)/RS(48,34)/"
                                    "6xRS(92,72) on the GPU, dump978 scan-loop rules on the host; parity unpinned (dump978 is un-vendored)"
                                    % (npieces * 64),
                        "bytes_per_gpu": int(dev.numel()), "sharding": "replicas only: one independent stream per GPU, no collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic("uat978:%d" % dev.numel()), "kernel": "uat_scan_iq_kernel",
-                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": int(alg_bytes)},
-            "frames_per_step": nframes_all, "demod_kernel_ms": round(demod_ms / args.steps, 4), "matches_per_step_rank0": int(matches),
+            "roofline": scan_roof,
+            "frames_per_step": nframes_all, "demod_kernel_ms": round(demod_k, 4), "matches_per_step_rank0": int(matches),
             "host_wall_ms_last_step": tm["host_wall_ms"],
         }
+        if demod_k > scan_k:
+            # latency-bound per-match kernel: its algorithmic bytes are the phases of the matches' frames, far below any HBM bound
+            out["dominant_kernel"] = {"kernel": "uat_demod_kernel", "kernel_ms": round(demod_k, 4), "matches": int(matches),
+                                      "us_per_1000_matches": round(demod_k * 1e3 / max(1, matches) * 1e3, 2),
+                                      "note": "latency-bound (dependent Reed-Solomon steps per match), not bandwidth-bound; the HBM roofline above is the scan kernel's"}
         if world == 1 and args.cpu_buffers > 0:
             from oracle import oracle_py as O
-            import numpy as np
             phi = O.phase_lut978()[first.view(np.uint16)]
             t1 = time.perf_counter()
             want, _ = O.process_buffer978(phi)
@@ -310,11 +547,10 @@ def main_uat978(args, rank, local_rank, world, dist, A, synth):
             out["cpu_baseline"] = {"value": round(first.size / 2 / dt / 1e6, 1), "unit": "Msamples/s", "cores": 1, "kind": "port",
                                    "sample": "oracle978 process_buffer over the first 64 MiB of the same stream (%.2f s), LUT map excluded; %d frames"
                                              % (dt, len(want))}
-        print(json.dumps(out), flush=True)
     u.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    del dev
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

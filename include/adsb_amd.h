@@ -38,6 +38,7 @@ extern "C" {
 #define ADSB_AMD_EHIP (-3)     /* HIP runtime error during a call */
 #define ADSB_AMD_ENOSPC (-4)   /* caller's output array too small (n_out holds the needed count) */
 #define ADSB_AMD_ESTATE (-5)   /* fetch without submit, etc. */
+#define ADSB_AMD_ENOMEM (-6)   /* the record regions an input would need do not fit in free device memory */
 
 /* RTLSDR::BufferLength (RTLSDR.hpp:55): the unit the reference demodulates independently. */
 #define ADSB_AMD_REF_BUFFER_BYTES 262144u
@@ -129,6 +130,11 @@ int adsb_amd_scan_1090_submit(adsb_amd_ctx_t* ctx, const void* iq_device, size_t
                               void* hip_stream, int slot);
 /* Waits for the slot; *records points into context-owned pinned memory, valid until the next submit on that slot. */
 int adsb_amd_scan_1090_fetch(adsb_amd_ctx_t* ctx, int slot, const adsb_amd_record_t** records, size_t* n);
+/* The same wait, but the sorted records are copied device-to-device into `dst_device` (room for `cap` records, same GPU) on
+ * `hip_stream` (NULL: an internal stream, and the call returns after the copy has completed): for consumers that stay on the
+ * GPU, e.g. the RCCL gather of the sharded recorded-file case.  ADSB_AMD_ENOSPC when cap is too
+ * small (*n holds the count) or when a chunk region overflowed (use adsb_amd_scan_1090_fetch, which repeats the scan). */
+int adsb_amd_scan_1090_fetch_device(adsb_amd_ctx_t* ctx, int slot, void* dst_device, size_t cap, void* hip_stream, size_t* n);
 /* Device time of the last completed scan on `slot`: the demodulation kernel alone, and submit-to-records-on-host. */
 int adsb_amd_scan_1090_timing(adsb_amd_ctx_t* ctx, int slot, float* scan_kernel_ms, float* total_ms);
 
@@ -153,6 +159,8 @@ void adsb_amd_resolver_set_sample_clock(adsb_amd_resolver_t* r, int64_t t0_ns, u
 long adsb_amd_resolver_feed(adsb_amd_resolver_t* r, const adsb_amd_record_t* records, size_t n, size_t samples_per_buffer,
                             size_t nbuffers, adsb_amd_on_changed_fn cb, void* user);
 size_t adsb_amd_resolver_aircraft_count(const adsb_amd_resolver_t* r);
+/* An adsb_amd_on_changed_fn that only counts: *(uint64_t*)user += 1 per call (IListener::OnChanged stand-in for rate runs). */
+void adsb_amd_count_callback(void* user, const adsb_amd_frame_t* frame, const adsb_amd_aircraft_t* aircraft);
 
 /* ---------------------------------------------------------------- both: one HandleData-shaped call */
 /* ADSB1090Handler as a whole (ADSB1090.cpp:99-244): create/destroy = ctor/dtor (:144-154), handle_data = HandleData (:158-175). */
@@ -185,8 +193,8 @@ long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* path, size_
  *   extern "C" void dump_raw_message(char, uint8_t*, int, int)               uat2json-wrapper.cpp:14 (the up-call, host's)
  * The arithmetic behind process_buffer is the un-vendored dump978 module: this side restates the published
  * legacy algorithm; parity unpinned (checked against oracle/oracle978.c only).
- * Division of work: phases (LUT), sign of the phase difference, every 18-bit sync match, the 36-bit sync re-check and the
- * frame slicing run on the GPU; Reed-Solomon and the order-dependent scan-loop rules run on the host.
+ * Division of work: phases (LUT), sign of the phase difference, every 18-bit sync match, the 36-bit sync re-check, the
+ * frame slicing and the Reed-Solomon decode run on the GPU; only the order-dependent scan-loop rules run on the host.
  * ===================================================================================================================*/
 typedef struct adsb_amd_uat adsb_amd_uat_t;
 

@@ -27,9 +27,9 @@ ON_CHANGED = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
 
 EXPORTS = [
     "adsb_amd_version", "adsb_amd_create", "adsb_amd_destroy", "adsb_amd_last_error", "adsb_amd_scan_1090",
-    "adsb_amd_scan_1090_submit", "adsb_amd_scan_1090_fetch", "adsb_amd_scan_1090_timing", "adsb_amd_magnitude_1090",
+    "adsb_amd_scan_1090_submit", "adsb_amd_scan_1090_fetch", "adsb_amd_scan_1090_fetch_device", "adsb_amd_scan_1090_timing", "adsb_amd_magnitude_1090",
     "adsb_amd_resolver_create", "adsb_amd_resolver_destroy", "adsb_amd_resolver_set_sample_clock", "adsb_amd_resolver_feed",
-    "adsb_amd_resolver_aircraft_count", "adsb_amd_handler_create", "adsb_amd_handler_destroy", "adsb_amd_handler_last_error",
+    "adsb_amd_resolver_aircraft_count", "adsb_amd_count_callback", "adsb_amd_handler_create", "adsb_amd_handler_destroy", "adsb_amd_handler_last_error",
     "adsb_amd_handler_set_sample_clock", "adsb_amd_handler_handle_data", "adsb_amd_handler_replay_file", "adsb_amd_host_alloc", "adsb_amd_host_free",
     "adsb_amd_uat_create", "adsb_amd_uat_destroy", "adsb_amd_uat_last_error", "adsb_amd_uat_handle_data", "adsb_amd_uat_set_carry_full",
     "adsb_amd_uat_stream_state", "adsb_amd_uat_process_phases", "adsb_amd_uat_process_iq", "adsb_amd_uat_timing", "adsb_amd_uat_host_timing", "adsb_amd_uat_phase_lut",
@@ -65,6 +65,7 @@ def lib():
         L.adsb_amd_scan_1090.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.adsb_amd_scan_1090_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
         L.adsb_amd_scan_1090_fetch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.adsb_amd_scan_1090_fetch_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
         L.adsb_amd_scan_1090_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.adsb_amd_magnitude_1090.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.adsb_amd_resolver_create.restype = C.c_void_p
@@ -174,6 +175,12 @@ class Scanner:
         arr = np.frombuffer(buf, dtype=RECORD_DTYPE)
         return arr.copy() if copy else arr
 
+    def fetch_device(self, slot, dst_ptr, cap_records, stream=0):
+        """Waits for the slot and copies its records device-to-device to `dst_ptr` (enqueued on `stream`); returns the count."""
+        n = C.c_size_t()
+        self._check(self._l.adsb_amd_scan_1090_fetch_device(self._h, slot, C.c_void_p(dst_ptr), cap_records, C.c_void_p(stream), C.byref(n)))
+        return n.value
+
     def timing(self, slot=0):
         a, b = C.c_float(), C.c_float()
         self._check(self._l.adsb_amd_scan_1090_timing(self._h, slot, C.byref(a), C.byref(b)))
@@ -202,11 +209,18 @@ class Resolver:
     def __del__(self):
         self.close()
 
-    def feed(self, records, samples_per_buffer, nbuffers, collect=True):
+    def feed(self, records, samples_per_buffer, nbuffers, collect=True, count_callbacks=False):
+        """collect: gather every callback's frame + aircraft snapshot (Python trampoline, slow); count_callbacks: fire the
+        library's own counting listener instead (the callback path at native speed); neither: no callback at all."""
         records = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
         col = _Collector()
-        n = self._l.adsb_amd_resolver_feed(self._h, records.ctypes.data, records.size, samples_per_buffer, nbuffers,
-                                           C.cast(col.cb, C.c_void_p) if collect else None, None)
+        cb, user = (C.cast(col.cb, C.c_void_p), None) if collect else (None, None)
+        counter = C.c_uint64(0)
+        if count_callbacks and not collect:
+            cb, user = C.cast(self._l.adsb_amd_count_callback, C.c_void_p), C.cast(C.pointer(counter), C.c_void_p)
+        n = self._l.adsb_amd_resolver_feed(self._h, records.ctypes.data, records.size, samples_per_buffer, nbuffers, cb, user)
+        if count_callbacks and not collect and n >= 0:
+            assert counter.value == n, "one callback per accepted frame"
         if n < 0:
             raise AdsbAmdError("resolver_feed failed (%d)" % n)
         fr, ac = col.arrays()
@@ -236,13 +250,22 @@ class Handler1090:
     def __del__(self):
         self.close()
 
-    def handle_data(self, iq, buffer_bytes=0):
-        """HandleData(span<const u8>): returns (frames, aircraft), one row per OnChanged callback, in callback order."""
+    def handle_data(self, iq, buffer_bytes=0, collect=True):
+        """HandleData(span<const u8>): returns (frames, aircraft), one row per OnChanged callback, in callback order.
+        collect=False: the library's counting listener takes the callbacks (native speed); returns the accepted-frame count."""
         iq = np.ascontiguousarray(iq, dtype=np.uint8)
         col = _Collector()
-        n = self._l.adsb_amd_handler_handle_data(self._h, iq.ctypes.data, iq.size, buffer_bytes, C.cast(col.cb, C.c_void_p), None)
+        counter = C.c_uint64(0)
+        if collect:
+            cb, user = C.cast(col.cb, C.c_void_p), None
+        else:
+            cb, user = C.cast(self._l.adsb_amd_count_callback, C.c_void_p), C.cast(C.pointer(counter), C.c_void_p)
+        n = self._l.adsb_amd_handler_handle_data(self._h, iq.ctypes.data, iq.size, buffer_bytes, cb, user)
         if n < 0:
             raise AdsbAmdError("handle_data failed (%d): %s" % (n, self._l.adsb_amd_handler_last_error(self._h).decode()))
+        if not collect:
+            assert counter.value == n
+            return n
         return col.arrays()
 
     def replay_file(self, path, first_buffer=0, max_buffers=2**62, collect=True):

@@ -53,6 +53,7 @@ struct Slot
 struct adsb_amd_ctx
 {
     int         device = 0;
+    uint32_t    nxcd = 8, ncu = 256; // topology of the device, read once at create
     hipStream_t stream = nullptr, copy_stream = nullptr;
     uint32_t*   crc_tab = nullptr;
     uint16_t*   lut978  = nullptr;
@@ -141,6 +142,8 @@ int make_args(adsb_amd_ctx* c, const void* iq_device, size_t nbytes, size_t buff
     if (total > 0x7FFFFFFFull) return fail(c, ADSB_AMD_EINVAL, "input too large for one scan call");
     a->total_chunks = (uint32_t)total;
     a->crc_tab      = c->crc_tab;
+    a->nxcd         = c->nxcd;
+    a->ncu          = c->ncu;
     return ADSB_AMD_OK;
 }
 
@@ -197,6 +200,15 @@ extern "C" int adsb_amd_create(adsb_amd_ctx_t** out, int device)
         return ADSB_AMD_ENODEV;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    {
+        // XCD-aware chunk ranges and the persistent grid follow the device's own topology (8 XCDs x 32 CUs on MI355X; other
+        // partition modes expose fewer).  Only speed depends on these numbers, results do not.
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->ncu = (uint32_t)v;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, device) == hipSuccess && v > 0) c->nxcd = (uint32_t)v;
+        else c->nxcd = 1;
+        if (c->nxcd > kMaxXcd) c->nxcd = kMaxXcd;
+    }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
 
@@ -207,8 +219,8 @@ extern "C" int adsb_amd_create(adsb_amd_ctx_t** out, int device)
     for (Slot& s : c->slot)
     {
         if ((e = hipMalloc(&s.total_d, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(total)", e);
-        if ((e = hipMalloc(&s.work_d, 64 * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(work)", e);
-        if ((e = hipMemset(s.work_d, 0, 64 * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(work)", e);
+        if ((e = hipMalloc(&s.work_d, kWorkCounters * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(work)", e);
+        if ((e = hipMemset(s.work_d, 0, kWorkCounters * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(work)", e);
         if ((e = hipHostMalloc(&s.total_h, 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(total)", e);
         if ((e = hipEventCreate(&s.ev_begin)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreate(&s.ev_scan0)) != hipSuccess) return bail("hipEventCreate", e);
@@ -267,53 +279,99 @@ extern "C" int adsb_amd_scan_1090_submit(adsb_amd_ctx_t* c, const void* iq_devic
     return ADSB_AMD_OK;
 }
 
-extern "C" int adsb_amd_scan_1090_fetch(adsb_amd_ctx_t* c, int slot, const adsb_amd_record_t** records, size_t* n)
+namespace
 {
-    if (!c) return ADSB_AMD_EINVAL;
-    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
-    Slot& s = c->slot[slot];
-    if (!s.pending) return fail(c, ADSB_AMD_ESTATE, "fetch without submit");
+// Body of fetch; the caller clears `pending` whatever the outcome, so a failed sync or copy never wedges the slot.
+int fetch_slot(adsb_amd_ctx* c, Slot& s)
+{
     HIP_TRY(c, hipSetDevice(c->device));
     for (;;)
     {
         HIP_TRY(c, hipEventSynchronize(s.ev_done));
         if (s.total_h[1] == 0) break;
         // A chunk produced more records than its region holds (dense noise, adversarial input): repeat with regions
-        // eight times larger, up to the hard bound of two records per preamble position.
+        // eight times larger, up to the hard bound of two records per preamble position -- as long as the two record
+        // arrays (regions + dense) still fit in free device memory; beyond that the call fails with ADSB_AMD_ENOMEM instead of
+        // leaning on hipMalloc to refuse.
         size_t cap = s.cap_per_chunk * 8;
         if (cap > (size_t)2 * kChunk) cap = (size_t)2 * kChunk;
-        if (cap == s.cap_per_chunk)
+        if (cap == s.cap_per_chunk) return fail(c, ADSB_AMD_EHIP, "record overflow at the maximum region size (internal error)");
+        const size_t nch  = s.args.total_chunks ? s.args.total_chunks : 1;
+        const size_t need = 2 * nch * cap * sizeof(adsb_amd_record_t), have = 2 * s.chunks_cap * s.cap_per_chunk * sizeof(adsb_amd_record_t);
+        size_t       free_b = 0, total_b = 0;
+        HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+        if (need > free_b + have)
         {
-            s.pending = false;
-            return fail(c, ADSB_AMD_EHIP, "record overflow at the maximum region size (internal error)");
+            c->error = "record regions would need " + std::to_string(need >> 20) + " MiB (" + std::to_string(cap) + " records per chunk), device has " +
+                       std::to_string((free_b + have) >> 20) + " MiB free: split the input into smaller scan calls";
+            return ADSB_AMD_ENOMEM;
         }
         int rc = ensure_slot(c, s, s.args.total_chunks, cap);
         if (rc == ADSB_AMD_OK) rc = enqueue(c, s);
-        if (rc)
-        {
-            s.pending = false;
-            return rc;
-        }
+        if (rc) return rc;
     }
     s.nrecords = s.total_h[0];
     int rc     = ensure_host(c, s, s.nrecords);
-    if (rc)
-    {
-        s.pending = false;
-        return rc;
-    }
+    if (rc) return rc;
     if (s.nrecords)
     {
         HIP_TRY(c, hipMemcpyAsync(s.host, s.dense, s.nrecords * sizeof(adsb_amd_record_t), hipMemcpyDeviceToHost, c->copy_stream));
         HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     }
-    s.pending = false;
-    s.timed   = true;
+    s.timed = true;
     (void)hipEventElapsedTime(&s.scan_ms, s.ev_scan0, s.ev_scan1);
     (void)hipEventElapsedTime(&s.total_ms, s.ev_begin, s.ev_done);
+    return ADSB_AMD_OK;
+}
+} // namespace
+
+/* The returned pointer aims into the slot's page-locked result buffer: it stays valid until the next submit on this slot
+ * (a later fetch may have to grow that buffer, which moves it). */
+extern "C" int adsb_amd_scan_1090_fetch(adsb_amd_ctx_t* c, int slot, const adsb_amd_record_t** records, size_t* n)
+{
+    if (!c) return ADSB_AMD_EINVAL;
+    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    Slot& s = c->slot[slot];
+    if (!s.pending) return fail(c, ADSB_AMD_ESTATE, "fetch without submit");
+    const int rc = fetch_slot(c, s);
+    s.pending    = false;
+    if (rc) return rc;
     if (records) *records = s.host;
     if (n) *n = s.nrecords;
     return ADSB_AMD_OK;
+}
+
+/* Device-side delivery of a slot's result: waits for the scan and copies its sorted records into `dst_device` (device memory
+ * of the same GPU, room for `cap` records) on `hip_stream` (NULL: the context's copy stream; the call returns after the copy
+ * has been enqueued there, and synchronises only in the NULL case).  For consumers that keep working on the GPU -- the
+ * multi-GPU gather sends the records to the root rank over RCCL without a host bounce.  The slot stays fetched afterwards. */
+extern "C" int adsb_amd_scan_1090_fetch_device(adsb_amd_ctx_t* c, int slot, void* dst_device, size_t cap, void* hip_stream, size_t* n)
+{
+    if (!c) return ADSB_AMD_EINVAL;
+    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    Slot& s = c->slot[slot];
+    if (!s.pending) return fail(c, ADSB_AMD_ESTATE, "fetch without submit");
+    auto body = [&]() -> int {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipEventSynchronize(s.ev_done));
+        if (s.total_h[1] != 0) return fail(c, ADSB_AMD_ENOSPC, "a chunk region overflowed: use adsb_amd_scan_1090_fetch, which repeats the scan with larger regions");
+        s.nrecords = s.total_h[0];
+        if (n) *n = s.nrecords;
+        if (s.nrecords > cap) return fail(c, ADSB_AMD_ENOSPC, "destination too small");
+        if (s.nrecords)
+        {
+            hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->copy_stream;
+            HIP_TRY(c, hipMemcpyAsync(dst_device, s.dense, s.nrecords * sizeof(adsb_amd_record_t), hipMemcpyDeviceToDevice, st));
+            if (!hip_stream) HIP_TRY(c, hipStreamSynchronize(st));
+        }
+        s.timed = true;
+        (void)hipEventElapsedTime(&s.scan_ms, s.ev_scan0, s.ev_scan1);
+        (void)hipEventElapsedTime(&s.total_ms, s.ev_begin, s.ev_done);
+        return ADSB_AMD_OK;
+    };
+    const int rc = body();
+    s.pending    = false;
+    return rc;
 }
 
 extern "C" int adsb_amd_scan_1090_timing(adsb_amd_ctx_t* c, int slot, float* scan_kernel_ms, float* total_ms)
@@ -433,8 +491,12 @@ extern "C" long adsb_amd_handler_handle_data(adsb_amd_handler_t* h, const uint8_
 {
     if (!h) return ADSB_AMD_EINVAL;
     h->error.clear();
-    adsb_amd_ctx* c  = h->ctx;
-    int           rc = stage_input(c, iq_host, nbytes);
+    adsb_amd_ctx* c = h->ctx;
+    if (!iq_host && nbytes) return fail(c, ADSB_AMD_EINVAL, "iq_host is NULL");
+    // libadsb calls HandleData from its transport's consumer thread (RTLSDR.hpp:470-473) and HIP's current device is per
+    // thread: select this handler's device before anything is allocated or copied
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = stage_input(c, iq_host, nbytes);
     if (rc) return rc;
     if ((rc = adsb_amd_scan_1090_submit(c, c->staging, nbytes, buffer_bytes, c->stream, 0))) return rc;
     const adsb_amd_record_t* rec = nullptr;
@@ -534,5 +596,11 @@ extern "C" long adsb_amd_resolver_feed(adsb_amd_resolver_t* r, const adsb_amd_re
 {
     if (!r) return ADSB_AMD_EINVAL;
     return r->impl.feed(records, n, samples_per_buffer, nbuffers, cb, user);
+}
+/* A listener that only counts: *(uint64_t*)user += 1 per accepted frame.  For rate measurements through the callback path
+ * without a foreign-language trampoline in the loop. */
+extern "C" void adsb_amd_count_callback(void* user, const adsb_amd_frame_t* /*frame*/, const adsb_amd_aircraft_t* /*aircraft*/)
+{
+    if (user) ++*static_cast<uint64_t*>(user);
 }
 extern "C" size_t adsb_amd_resolver_aircraft_count(const adsb_amd_resolver_t* r) { return r ? r->impl.aircraft_count() : 0; }

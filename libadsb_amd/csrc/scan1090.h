@@ -36,8 +36,14 @@ struct ScanArgs
     adsb_amd_record_t* chunk_records; // total_chunks * cap
     uint32_t*          chunk_counts;  // total_chunks
     uint32_t           cap;           // records per chunk region
-    uint32_t*          work_counters; // one per XCD at [32 * xcd] (own cache line each), zero when the scan starts; the ordering pass zeroes them again
+    uint32_t*          work_counters; // kSubRanges per XCD, counter c at [32 * c] (own cache line each), zero when the scan starts; the ordering pass zeroes them again
+    uint32_t           nxcd;          // XCDs of the device (hipDeviceAttributeNumberOfXccs; 8 on MI355X), <= kMaxXcd
+    uint32_t           ncu;           // compute units of the device (256 on MI355X)
 };
+
+constexpr uint32_t kSubRanges   = 4;  // work counters per XCD
+constexpr uint32_t kMaxXcd      = 16;
+constexpr uint32_t kWorkCounters = kSubRanges * kMaxXcd;
 
 inline uint32_t chunks_per_buffer(uint32_t buf_samples)
 {

@@ -38,7 +38,6 @@ namespace adsb_amd
 namespace
 {
 
-constexpr uint32_t kSubRanges = 4; // work counters per XCD
 constexpr int kQueueCap = 512; // stage-1 survivors processed per pass (a chunk rarely has more than ~60)
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -597,7 +596,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
     // XCD-aware chunk order: workgroups b and b+8 share an XCD (round-robin dispatch), so give every XCD one
     // contiguous range of chunks and let its workgroups walk that range together -> halo re-reads hit its L2.
     // Each XCD range is cut into kSubRanges pieces with a work counter each, so that no more than 128 waves share a counter.
-    const uint32_t nxcd  = 8;
+    const uint32_t nxcd  = a.nxcd;
     const uint32_t xcd   = blockIdx.x % nxcd;
     const uint32_t wg    = blockIdx.x / nxcd;          // index of this workgroup among those of its XCD
     const uint32_t sub   = wg % kSubRanges;
@@ -853,7 +852,7 @@ __global__ __launch_bounds__(256) void block_sums_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ work_counters)
 {
     __shared__ uint32_t wave_tot[4];
-    if (blockIdx.x == 0 && threadIdx.x < 8 * kSubRanges) work_counters[threadIdx.x * 32u] = 0; // the scan before this pass is done with them; ready for the next
+    if (blockIdx.x == 0 && threadIdx.x < kWorkCounters) work_counters[threadIdx.x * 32u] = 0; // the scan before this pass is done with them; ready for the next
     const uint32_t      c = blockIdx.x * kOrderBlock + threadIdx.x;
     uint32_t            v = (c < nchunks) ? counts[c] : 0u;
     if (v > cap)
@@ -967,12 +966,13 @@ __global__ __launch_bounds__(256) void phase978_kernel(const uint8_t* __restrict
 hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream)
 {
     if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
-    // persistent single-wave workgroups: enough to fill 256 CUs at the LDS-limited occupancy (16 per CU), multiple of 8 (XCDs)
+    // persistent single-wave workgroups: enough to fill every CU at the LDS-limited occupancy (16 per CU)
 #ifndef ADSB_AMD_WAVES_PER_CU
 #define ADSB_AMD_WAVES_PER_CU 16
 #endif
-    uint32_t grid = 256u * ADSB_AMD_WAVES_PER_CU;
-    if (grid > a.total_chunks) grid = ((a.total_chunks + 8u * kSubRanges - 1u) / (8u * kSubRanges)) * 8u * kSubRanges;
+    const uint32_t unit = a.nxcd * kSubRanges; // the grid is a multiple of this: every (XCD, sub-range) gets the same number of waves
+    uint32_t       grid = (a.ncu * ADSB_AMD_WAVES_PER_CU / unit) * unit;
+    if (grid > a.total_chunks) grid = ((a.total_chunks + unit - 1u) / unit) * unit;
     hipLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
     return hipGetLastError();
 }

@@ -5,13 +5,18 @@
 // Everything after that restates the published dump978 legacy demodulator (un-vendored in the reference):
 // parity unpinned, GPU == oracle/oracle978.c is what the tests check.
 //
-// Round-1 shape (correct first, not yet tuned): three small kernels over a device-resident stream.
-//   K1 uat_sign_kernel     one sample per lane: two LUT gathers, wrapped 16-bit difference, __ballot -> 1 bit per sample
-//   K2 uat_match_kernel    one 32-sample word per lane, bit-parallel: the 18 check bits sit 2 samples apart, so a match at
-//                          sample i is AND_k (S >> 2k) == pattern bit k; 18 funnel shifts shared by both sync words
-//   K3 uat_demod_kernel    one wave per candidate (the host may also ask for further sample indices, see uat978_host.cpp): 36-bit sync re-check against the data-derived centre for the candidate
-//                          and for the next sample (the reference tries both), then the frame bits sliced at that centre
-// The sequential part (which candidate the scan loop reaches, Reed-Solomon, frame choice, skip-ahead) runs on the host.
+// Kernels over a device-resident stream:
+//   uat_scan_iq_kernel     batch path (u8 IQ in HBM): persistent 1024-lane workgroups, the whole 128 KiB phase LUT in LDS
+//                          (bank-swizzled), wave-owned 2048-sample spans with a register prefetch of the next span: phases,
+//                          wrapped 16-bit differences, sign bits, both 18-bit check words -- bound by the HBM read (2 B/sample)
+//   uat_sign_kernel +      the same two steps for a buffer of *phases* (the process_buffer seam and the 65 536-entry staging
+//   uat_match_kernel       rounds of HandleData; small inputs)
+//   uat_demod_kernel       one wave per match (the host may also ask for further sample indices, see uat978_host.cpp): the
+//                          36-bit sync re-check against the data-derived centre for the match and for the next sample (the
+//                          reference tries both), the frame sliced at that centre, and its Reed-Solomon decode with the whole
+//                          wave on one code word (rs978.h: Berlekamp-Massey, Chien, Forney with libfec's conventions)
+//   uat_order_*            counting sort of the matches by stream position, on the device
+// Only the order-dependent scan-loop rules (which match the loop reaches, frame choice, skip-ahead) run on the host.
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>

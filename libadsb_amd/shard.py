@@ -1,15 +1,22 @@
 """Multi-GPU use of the scanner: independent reference buffers are split over ranks, records come back to one rank.
 
 Every 262144-byte reference buffer is demodulated independently, so a recording is partitioned at buffer
-granularity with no halo and no exchange on the data path.  The only communication is the gather of the (small) record
-arrays to the rank that runs the sequential resolver: an all_gather of the per-rank counts followed by an all_gather of
-the padded record bytes -- RCCL over xGMI with backend "nccl", gloo in the CPU tests.
+granularity with no halo and no exchange on the data path (rank r takes buffers [r*B/N, (r+1)*B/N), a trailing partial
+buffer is never delivered: reference RTLSDR.hpp:419-442).  The only communication is the gather of the (small) record
+arrays to the rank that runs the sequential resolver -- RCCL over xGMI with backend "nccl", gloo in the CPU tests:
+
+  gather_records      every rank receives the whole stream (all_gather of counts, then of padded bytes)
+  RootGather          only the root receives it: one fixed-size dist.gather per step, the record count travels in a
+                      32-byte header in front of the records, so there is no separate count exchange; on "nccl" the payload
+                      goes device to device (the scanner copies its sorted records straight into the send buffer)
 """
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import RECORD_DTYPE
+
+REC = RECORD_DTYPE.itemsize  # 32
 
 
 def shard_range(nbuf_total, rank, world):
@@ -31,11 +38,77 @@ def gather_records(records, first_buffer, group=None, device=None):
     dist.all_gather(counts, count, group=group)
     counts = [int(c.item()) for c in counts]
     cap = max(max(counts), 1)
-    payload = torch.zeros(cap * RECORD_DTYPE.itemsize, dtype=torch.uint8)
+    payload = torch.zeros(cap * REC, dtype=torch.uint8)
     if len(rec):
-        payload[:len(rec) * RECORD_DTYPE.itemsize] = torch.from_numpy(rec.view(np.uint8).reshape(-1))
+        payload[:len(rec) * REC] = torch.from_numpy(rec.view(np.uint8).reshape(-1))
     payload = payload.to(device)
     parts = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(parts, payload, group=group)
-    out = [np.frombuffer(p.cpu().numpy().tobytes()[:n * RECORD_DTYPE.itemsize], dtype=RECORD_DTYPE) for p, n in zip(parts, counts)]
+    out = [np.frombuffer(p.cpu().numpy().tobytes()[:n * REC], dtype=RECORD_DTYPE) for p, n in zip(parts, counts)]
     return np.concatenate(out) if out else np.zeros(0, RECORD_DTYPE)
+
+
+class RootGather:
+    """Per-step gather of every rank's sorted records to rank `root`, for the sharded recorded-file job.
+
+    Each rank owns a send buffer of 1 + cap records: record 0 is a header {count, first_buffer} and the scanner's records
+    follow.  One dist.gather of that fixed size per step; the root then copies exactly count_r records of every part to
+    page-locked host memory, rebases their buffer indices to the recording and hands the rank-ordered stream to the
+    resolver.  `cap` is fixed for the job (the caller sizes it from a first scan, with slack); a step that exceeds it
+    raises rather than truncating.
+    """
+
+    def __init__(self, cap_records, root=0, group=None, device=None):
+        self.group, self.root, self.cap = group, root, int(cap_records)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.on_device = dist.get_backend(group) == "nccl"
+        self.device = device or (torch.device("cuda", torch.cuda.current_device()) if self.on_device else torch.device("cpu"))
+        nbytes = (1 + self.cap) * REC
+        self.send = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self.parts = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(self.world)] if self.rank == root else None
+        self.host = torch.zeros(self.world * nbytes, dtype=torch.uint8).pin_memory() if (self.rank == root and self.on_device) else None
+        self._hdr = torch.zeros(REC, dtype=torch.uint8).pin_memory() if self.on_device else torch.zeros(REC, dtype=torch.uint8)
+
+    def records_ptr(self):
+        """Device (or host) address where this rank's records of the step go: right behind the header."""
+        return self.send.data_ptr() + REC
+
+    def host_records_view(self):
+        """gloo/CPU mode: numpy view of the record area of the send buffer (fill it, then call gather)."""
+        return self.send.numpy()[REC:].view(RECORD_DTYPE)
+
+    def gather(self, count, first_buffer):
+        """Collective.  `count` records of this rank already lie at records_ptr().  Returns on the root the concatenated
+        RECORD_DTYPE array with recording-wide buffer indices (a view of internal page-locked memory, valid until the
+        next call), elsewhere None."""
+        if count > self.cap:
+            raise RuntimeError("rank %d produced %d records, send buffer holds %d" % (self.rank, count, self.cap))
+        hdr = self._hdr.numpy().view(np.uint64)
+        hdr[0], hdr[1] = count, first_buffer
+        self.send[:REC].copy_(self._hdr, non_blocking=True)
+        dist.gather(self.send, self.parts, dst=self.root, group=self.group)
+        if self.rank != self.root:
+            return None
+        # headers first (world x 32 bytes), then exactly the bytes that hold records
+        heads = torch.stack([p[:REC] for p in self.parts]).cpu().numpy().view(np.uint64).reshape(self.world, -1)
+        counts = [int(h[0]) for h in heads]
+        firsts = [int(h[1]) for h in heads]
+        total = sum(counts)
+        if self.on_device:
+            out = self.host[:total * REC]
+            at = 0
+            for p, n in zip(self.parts, counts):
+                if n:
+                    out[at:at + n * REC].copy_(p[REC:REC + n * REC], non_blocking=True)
+                at += n * REC
+            torch.cuda.current_stream().synchronize()
+            rec = out.numpy().view(RECORD_DTYPE)
+        else:
+            rec = np.concatenate([p.numpy()[REC:REC + n * REC].view(RECORD_DTYPE) for p, n in zip(self.parts, counts)]) if total else np.zeros(0, RECORD_DTYPE)
+            rec = rec.copy()
+        at = 0
+        for n, f in zip(counts, firsts):
+            if n and f:
+                rec["buffer"][at:at + n] += f
+            at += n
+        return rec

@@ -93,6 +93,10 @@ int      oracle1090_cpr_nl(double lat);                          /* :993-1055 */
 /* global CPR decode (:1079-1121); returns 0 when the latitude zones disagree (state left untouched) */
 int      oracle1090_decode_cpr(double even_lat, double even_lon, double odd_lat, double odd_lon, int use_even, int32_t* lat1e7, int32_t* lon1e7);
 
+/* expected1090.c: the adsb_amd_record_t array (include/adsb_amd.h; 32 bytes each) a scan call over `iq` must produce, from the
+ * probes above; buffers spread over `nthreads` threads.  Returns the total count (may exceed cap), (size_t)-1 on failure. */
+size_t oracle1090_expected_records(const uint8_t* iq, size_t nbytes, size_t buffer_bytes, void* out, size_t cap, int nthreads);
+
 /* UAT978 phase LUT (UAT978.cpp:76-100): 65536 entries indexed by I | Q<<8 */
 void oracle978_phase_lut(uint16_t* lut65536);
 

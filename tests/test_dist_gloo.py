@@ -30,6 +30,22 @@ if rank == 0:
     ofr, oac = H.oracle_run(full, BB)
     H.assert_streams_equal(fr, ac, ofr, oac)
     print('OK', n, len(allrec))
+# the per-step form bench.py uses: fixed-size gather to the root only, count in the header
+rg = shard.RootGather(1000)  # the same capacity on every rank (bench.py agrees on it with an all_reduce MAX)
+for step in range(2):
+    rg.host_records_view()[:len(local)] = local
+    got = rg.gather(len(local), first)
+    if rank == 0:
+        H.assert_records_equal(got, allrec)
+    else:
+        assert got is None
+try:
+    shard.RootGather(3).gather(4, 0)
+    raise SystemExit('an over-full send buffer must raise')
+except RuntimeError:
+    pass
+if rank == 0:
+    print('ROOT-GATHER-OK')
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -52,4 +68,30 @@ def test_two_rank_gather_and_resolve(tmp_path, native_libs):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29517", str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    assert "OK" in out.stdout
+    assert "OK" in out.stdout and "ROOT-GATHER-OK" in out.stdout
+
+
+def test_bench_started_bare_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` with no RANK in the environment (how the driver starts it) must start the N ranks as child
+    processes of torch.distributed.run on 127.0.0.1 and hand their return code back; with RANK set it must not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("RANK", raising=False)
+    try:
+        bench.main()
+        raise AssertionError("main() must exit with the children's code")
+    except SystemExit as e:
+        assert e.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -204,9 +204,9 @@ def test_replay_file_matches_oracle_and_drops_the_partial_buffer(native_libs, tm
     h.close()
 
 
-def test_full_size_1gib_properties_and_sampled_oracle_equality(scanner):
+def test_full_size_1gib_equals_oracle_on_every_buffer(scanner):
     """BASELINE configs[1]+[2] at full size: 4096 reference buffers (1 GiB) in one scan.  Size-independent properties
-    (shard invariance, strict order, parity consistency) plus exact equality with the oracle on a random sample of buffers."""
+    (shard invariance, strict order, parity consistency) plus exact equality with the oracle on all 4096 buffers."""
     nbuf = 4096
     iq, injected = synth.fill_range(0, nbuf, nthreads=16)
     full = scanner.scan(iq, BB)
@@ -224,12 +224,9 @@ def test_full_size_1gib_properties_and_sampled_oracle_equality(scanner):
     for r in stateless[:: max(1, len(stateless) // 2000)]:
         msg, nb = bytes(r["msg"]), int(r["nbits"])
         assert O.lib().oracle1090_checksum(msg, nb) == int.from_bytes(msg[nb // 8 - 3: nb // 8], "big")
-    rng = np.random.default_rng(2024)
-    for b in rng.choice(nbuf, 48, replace=False):
-        want = H.expected_records(iq[b * BB:(b + 1) * BB], BB)
-        got = full[full["buffer"] == b].copy()
-        got["buffer"] = 0
-        H.assert_records_equal(got, want)
+    # every one of the 4096 buffers against the oracle: the expected record array is built in C (oracle/expected1090.c,
+    # the same rules as helpers.records_from_probe, buffers spread over threads)
+    H.assert_records_equal(full, O.expected_records(iq, BB, dtype=A.RECORD_DTYPE))
 
 
 @pytest.mark.parametrize("seed", range(5))
@@ -282,3 +279,128 @@ def test_fuzzed_threshold_cases(scanner, seed):
     ofr, oac = H.oracle_run(iq, BB)
     H.assert_streams_equal(fr, ac, ofr, oac)
     h.close()
+
+
+def test_expected_records_in_c_equal_the_python_rules():
+    # the two statements of the emission contract (tests/helpers.py and oracle/expected1090.c) agree, including on inputs
+    # that are all ties / all noise
+    for over in (dict(), dict(noise_amp=20), dict(pct_bitflip=100, pct_df17=50, pct_df11=50), dict(noise_amp=0, mean_spacing=600, amp_lo=3, amp_hi=12)):
+        iq, _ = synth.fill_range(17, 3, cfg=synth.default_cfg(**over))
+        H.assert_records_equal(O.expected_records(iq, BB, dtype=A.RECORD_DTYPE), H.expected_records(iq, BB))
+        H.assert_records_equal(O.expected_records(iq[:BB + 9000], 0, dtype=A.RECORD_DTYPE), H.expected_records(iq[:BB + 9000], 0))
+
+
+def test_handle_data_from_another_thread(native_libs):
+    """libadsb calls HandleData from its transport's consumer thread (RTLSDR.hpp:470-473), not from the thread that built the
+    handler; HIP's current device is per thread, so the entry point has to select the handler's device itself."""
+    import threading
+    iq, _ = synth.fill_range(60, 4)
+    h = A.Handler1090(0)
+    got, err = {}, []
+
+    def consumer():
+        try:
+            for b in range(4):
+                fr, ac = h.handle_data(iq[b * BB:(b + 1) * BB])
+                got[b] = (fr, ac)
+        except Exception as e:  # surfaced on the main thread
+            err.append(e)
+    t = threading.Thread(target=consumer)
+    t.start()
+    t.join()
+    assert not err, err
+    o = O.Oracle1090()
+    for b in range(4):
+        ofr, oac = o.handle_data(iq[b * BB:(b + 1) * BB])
+        H.assert_streams_equal(got[b][0], got[b][1], ofr, oac)
+    # and the replay entry point, which goes through the same staging path
+    h.close()
+
+
+def test_fetch_device_delivers_the_same_records(scanner):
+    import torch
+    iq, _ = synth.fill_range(300, 8)
+    d = torch.from_numpy(iq).cuda()
+    want = scanner.scan(iq, BB)
+    dst = torch.zeros((len(want) + 100) * 32, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    scanner.submit(d.data_ptr(), d.numel(), BB, st, 1)
+    n = scanner.fetch_device(1, dst.data_ptr(), len(want) + 100, st)
+    torch.cuda.synchronize()
+    assert n == len(want)
+    H.assert_records_equal(dst[:n * 32].cpu().numpy().view(A.RECORD_DTYPE), want)
+    scanner.submit(d.data_ptr(), d.numel(), BB, st, 1)
+    with pytest.raises(A.AdsbAmdError, match="too small"):
+        scanner.fetch_device(1, dst.data_ptr(), 10, st)
+    H.assert_records_equal(scanner.scan(iq, BB), want)  # the slot is usable again after the failed delivery
+
+
+def _run(cmd, timeout=900):
+    import os
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None)
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_sharded_file_step_two_ranks_rehearsal(native_libs, tmp_path):
+    """BASELINE configs[3] as bench.py runs it for --gpus N > 1, rehearsed with two ranks on this one GPU (gloo): started bare
+    (bench.py launches its own ranks), rank r scans its half of the recording, the records are gathered on rank 0 and resolved
+    there.  The gathered records and the callback stream must equal the oracle run over the whole recording."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = tmp_path / "stream.npz"
+    out = _run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--mib", "4", "--steps", "3", "--warmup", "1",
+                "--dump-stream", str(dump)])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["buffers_total"] == 32 and line["value"] > 0
+    z = np.load(dump)
+    whole, _ = synth.fill_range(0, 32)
+    H.assert_records_equal(z["records"], O.expected_records(whole, BB, dtype=A.RECORD_DTYPE))
+    ofr, oac = H.oracle_run(whole, BB)
+    H.assert_streams_equal(z["frames"], z["aircraft"], ofr, oac)
+    assert line["decoded_msgs_per_step"] == len(ofr)
+
+
+NCCL_WORLD1 = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import libadsb_amd as A
+from libadsb_amd import synth
+from libadsb_amd.shard import RootGather
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+BB = A.REF_BUFFER_BYTES
+iq, _ = synth.fill_range(5, 8)
+d = torch.from_numpy(iq).cuda()
+sc = A.Scanner(0)
+want = sc.scan(iq, BB)
+rg = RootGather(len(want) + 64)
+st = torch.cuda.current_stream()
+for first in (0, 40):
+    sc.submit(d.data_ptr(), d.numel(), BB, st.cuda_stream, 0)
+    n = sc.fetch_device(0, rg.records_ptr(), rg.cap, st.cuda_stream)
+    rec = rg.gather(n, first)
+    w = want.copy(); w["buffer"] += first
+    assert rec.dtype == w.dtype and np.array_equal(rec, w), "gathered records differ"
+print("NCCL-OK", len(want))
+dist.destroy_process_group()
+"""
+
+
+def test_root_gather_over_rccl_world_of_one(native_libs, tmp_path):
+    # the device path of the record gather (scanner -> send buffer -> dist.gather on "nccl" = RCCL -> page-locked host) with the
+    # one rank this box has; more ranks on one GPU are refused by RCCL, the N = 2 logic is covered by the gloo rehearsal above
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "nccl1.py"
+    script.write_text(NCCL_WORLD1 % {"root": root})
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                str(script)])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
+    assert "NCCL-OK" in out.stdout
