@@ -14,15 +14,23 @@ namespace adsb_amd
 // of one reference buffer out of an LDS-staged window of kChunk + kHalo samples.
 constexpr int kLanes      = 64;
 constexpr int kRowSamples = 512; // one 16-byte load per lane = 8 IQ samples per lane = 512 per wavefront
-#ifndef ADSB_AMD_ROWS
-#define ADSB_AMD_ROWS 8
-#endif
-constexpr int kRows       = ADSB_AMD_ROWS; // 1 KiB load rows per chunk (even: stage 1 walks 1024-position super-rows)
+constexpr int kRows       = 8;   // 1 KiB load rows per chunk
 constexpr int kChunk      = kRows * kRowSamples; // 4096 positions
 constexpr int kHalo       = 256;                 // >= 240 samples read past the last position, half a row
-constexpr int kFront      = 8;                   // u16 slots before the window; slot 7 = sample g0-1
-constexpr int kTileU16    = kFront + kChunk + kHalo + 8;
 constexpr int kFrameSpan  = 240;                 // (8 + 112) * 2 samples: reference loop bound (ADSB1090.cpp:772)
+
+// LDS image of a chunk's s = (I-127)^2 + (Q-127)^2 values: the two halves of the chunk are interleaved, dword q holds
+// (s[q] | s[q + 2048] << 16) for q = 0 .. 2047.  A packed 16-bit operation on dword q therefore works on two preamble
+// positions 2048 samples apart, and the operand "sample q + a" of BOTH positions is simply dword q + a, whatever the parity
+// of a: no funnel shifts, and every sliding intermediate (max(s[q], s[q+2]), ...) is computed once per dword and used at every
+// offset.  The image continues for kHalo more dwords, (s[2048 + m] | s[4096 + m] << 16): the low halves repeat the start of the
+// upper half, the high halves are the halo behind the chunk, so the 240-sample window of ANY position is one linear run of
+// halves: sample p of the chunk (0 <= p < kChunk + kHalo) lives at uint16_t index tile_index(p) = 2 (p % 2048) + p / 2048
+// for p < 4096 and 2 (p - 2048) + 1 beyond, i.e. consecutive samples of a window are always 2 halves apart.
+constexpr int kHalfChunk   = kChunk / 2;                    // 2048
+constexpr int kImageDwords = kHalfChunk + kHalo;            // 2304
+constexpr int kFrontSlot16 = 2 * kImageDwords;              // 4608: the sample just before the chunk (g0 - 1)
+constexpr int kTileDwords  = kImageDwords + 4;              // 2308 dwords = 9232 bytes
 
 struct ScanArgs
 {

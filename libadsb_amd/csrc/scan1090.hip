@@ -4,12 +4,14 @@
 // reference buffer.  It streams the 8.5 KiB of u8 IQ that those positions can touch with 16-byte
 // coalesced loads (the next chunk's loads are issued before the current chunk is processed, so HBM
 // latency hides behind the arithmetic), turns every I,Q pair into s = (I-127)^2 + (Q-127)^2 with packed
-// 16-bit math and parks s (u16) in a wave-private LDS window.  Everything after that works out of LDS:
+// 16-bit math and parks s (u16) in a wave-private LDS image with the two halves of the chunk interleaved
+// (scan1090.h): dword q = (s[q], s[q + 2048]).  Everything after that works out of LDS:
 //
 //   stage 1  (reference ADSB1090.cpp:782-783)  ten preamble comparisons per position, evaluated on s
 //            instead of on the magnitude: the reference LUT m = round(360*sqrt(s)) is strictly
 //            increasing on every reachable s, so <,> between magnitudes equal <,> between s values.
-//            Packed: two positions per VALU op, the ten comparisons folded into four "low < high" bounds.
+//            Packed: one VALU op works on two positions 2048 samples apart, operand "sample q+a" is dword q+a
+//            for every a, the ten comparisons fold into four "low < high" bounds with shared sliding maxima.
 //   stage 2  (:794-811) exact magnitudes for the ~1 % of positions that survive, dense over lanes.
 //   demod    (:814-881, 277-332) one candidate at a time, all 64 lanes: lane b slices bit b (and 64+b),
 //            the "copy the previous bit" and the phase-correction recurrences are resolved from
@@ -38,7 +40,7 @@ namespace adsb_amd
 namespace
 {
 
-constexpr int kQueueCap = 512; // stage-1 survivors processed per pass (a chunk rarely has more than ~60)
+constexpr int kQueueCap = 256; // stage-1 survivors processed per pass (a chunk rarely has more than ~60)
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short          i16x2 __attribute__((ext_vector_type(2)));
@@ -46,7 +48,6 @@ typedef short          i16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2    as_pk(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
 __device__ __forceinline__ uint32_t as_u32(u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_max(as_pk(a), as_pk(b))); }
-__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_min(as_pk(a), as_pk(b))); }
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u32(as_pk(a) - as_pk(b)); }
 
 // Two IQ samples (4 bytes I0 Q0 I1 Q1) -> (s0 | s1 << 16), s = (I-127)^2 + (Q-127)^2 saturated to 32767.
@@ -64,6 +65,27 @@ __device__ __forceinline__ uint32_t iq2_to_s2(uint32_t x)
     uint32_t       r;
     asm("v_pk_mad_i16 %0, %1, %1, %2 clamp" : "=v"(r) : "v"(dq), "v"(a));
     return r;
+}
+
+// (I_a, I_b) and (Q_a, Q_b) as zero-extended 16-bit pairs -> (s_a | s_b << 16), same arithmetic as iq2_to_s2
+__device__ __forceinline__ uint32_t pair_to_s2(uint32_t i16, uint32_t q16)
+{
+    const u16x2    c  = {127, 127};
+    const uint32_t di = as_u32(as_pk(i16) - c), dq = as_u32(as_pk(q16) - c);
+    const uint32_t a  = as_u32(as_pk(di) * as_pk(di));
+    uint32_t       r;
+    asm("v_pk_mad_i16 %0, %1, %1, %2 clamp" : "=v"(r) : "v"(dq), "v"(a));
+    return r;
+}
+
+// The same 4 bytes (two samples) of two rows, x from the lower half of the chunk and y from the upper -> two dwords of the image:
+// t0 = (s(x sample 0), s(y sample 0)), t1 = (s(x sample 1), s(y sample 1)).  v_perm_b32 picks one byte from each source
+// (selector 0..3 = bytes of the second operand, 4..7 = bytes of the first, 0x0C = zero), so pairing two rows costs the same six
+// operations per dword as unpacking two neighbouring samples.
+__device__ __forceinline__ void rows_to_s2(uint32_t x, uint32_t y, uint32_t& t0, uint32_t& t1)
+{
+    t0 = pair_to_s2(__builtin_amdgcn_perm(y, x, 0x0C040C00u), __builtin_amdgcn_perm(y, x, 0x0C050C01u));
+    t1 = pair_to_s2(__builtin_amdgcn_perm(y, x, 0x0C060C02u), __builtin_amdgcn_perm(y, x, 0x0C070C03u));
 }
 
 __device__ __forceinline__ uint32_t iq1_to_s(uint32_t i, uint32_t q)
@@ -315,10 +337,38 @@ struct BitMags
     int loA, hiA, loB, hiB;
 };
 
-// DetectOutOfPhase (:683-690) != 0 for the preamble at tile index w0 (j >= 1): needs exact magnitudes of m[j-1 .. j+10].
-__device__ __forceinline__ bool preamble_out_of_phase(const uint16_t* tile, int lane, int w0)
+// Where one candidate's samples live in the interleaved image (scan1090.h): sample t = 0 .. 239 of the window of chunk position
+// pos is the half at a0 + 2 t.  All members are wave-uniform.
+struct Win
 {
-    const int pre = mag_of_s(tile[w0 - 1 + (lane & 15)]); // lanes 0..15: m[j-1 .. j+14]
+    uint32_t a0;  // tile index (uint16_t units) of sample t = 0
+    uint32_t am1; // tile index of sample t = -1
+};
+
+__device__ __forceinline__ uint32_t tile_index(uint32_t pos) { return 2u * (pos & (uint32_t)(kHalfChunk - 1)) + (pos >> 11); } // pos < kChunk
+
+__device__ __forceinline__ Win make_win(uint32_t pos)
+{
+    Win w;
+    w.a0  = tile_index(pos);
+    // the sample in front of position 0 is the one in front of the chunk; the one in front of position 2048 is the last low half
+    w.am1 = pos == 0 ? (uint32_t)kFrontSlot16 : (pos == (uint32_t)kHalfChunk ? (uint32_t)(2 * (kHalfChunk - 1)) : w.a0 - 2u);
+    return w;
+}
+
+// s of the two samples of bit `lane` (t = 16 + 2 lane, +1) and of bit 64 + lane (another 128 samples on; lanes >= 48 repeat bit `lane`)
+__device__ __forceinline__ void load_bit_samples(const uint16_t* tile, const Win& w, int lane, bool has_b, uint32_t& sLoA, uint32_t& sHiA,
+                                                 uint32_t& sLoB, uint32_t& sHiB)
+{
+    const uint32_t ia = w.a0 + 32u + 4u * (uint32_t)lane, ib = has_b ? ia + 256u : ia;
+    sLoA = tile[ia]; sHiA = tile[ia + 2]; sLoB = tile[ib]; sHiB = tile[ib + 2];
+}
+
+// DetectOutOfPhase (:683-690) != 0 for the preamble of window w (j >= 1): needs exact magnitudes of m[j-1 .. j+10].
+__device__ __forceinline__ bool preamble_out_of_phase(const uint16_t* tile, int lane, const Win& w)
+{
+    const uint32_t t   = (uint32_t)(lane & 15); // lanes 0..15: m[j-1 .. j+14]
+    const int      pre = mag_of_s(tile[t == 0 ? w.am1 : w.a0 + 2u * (t - 1u)]);
     const int m_1 = __builtin_amdgcn_readlane(pre, 0), m1 = __builtin_amdgcn_readlane(pre, 2), m2 = __builtin_amdgcn_readlane(pre, 3);
     const int m3 = __builtin_amdgcn_readlane(pre, 4), m6 = __builtin_amdgcn_readlane(pre, 7), m7 = __builtin_amdgcn_readlane(pre, 8);
     const int m9 = __builtin_amdgcn_readlane(pre, 10), m10 = __builtin_amdgcn_readlane(pre, 11);
@@ -332,12 +382,11 @@ __device__ __forceinline__ bool preamble_out_of_phase(const uint16_t* tile, int 
 // yields its conditional record and, unless the preamble is out of phase, the retry would reproduce the same bits.
 // Returns 0 when the candidate is finished, 1 when the general demodulator has to run from scratch (nothing was
 // emitted), 2 when only its retry pass remains (the pass-1 record is already out).
-__device__ __forceinline__ int demod_strong_frame(const uint16_t* tile, int lane, const LaneTables& lt, Emit& e, int w0, uint32_t j)
+__device__ __forceinline__ int demod_strong_frame(const uint16_t* tile, int lane, const LaneTables& lt, Emit& e, const Win& w, uint32_t j)
 {
-    const bool     has_b = lane < 48;
-    const int      ia    = w0 + 16 + 2 * lane;
-    const int      ib    = has_b ? ia + 128 : ia;
-    const uint32_t sLoA = tile[ia], sHiA = tile[ia + 1], sLoB = tile[ib], sHiB = tile[ib + 1];
+    const bool has_b = lane < 48;
+    uint32_t   sLoA, sHiA, sLoB, sHiB;
+    load_bit_samples(tile, w, lane, has_b, sLoA, sHiA, sLoB, sHiB);
     if (__builtin_amdgcn_readfirstlane((int)(sLoA == sHiA))) return 0; // :839-846, dead on both passes
     const float    fA = __builtin_fabsf(mag_estimate(sLoA) - mag_estimate(sHiA));
     const float    fB = __builtin_fabsf(mag_estimate(sLoB) - mag_estimate(sHiB));
@@ -381,24 +430,23 @@ __device__ __forceinline__ int demod_strong_frame(const uint16_t* tile, int lane
         return 0;
     }
     emit_raw(e, lane, j, ba, bb, df, nbits, -1, ADSB_AMD_F_NEEDS_ICAO, syn);
-    if (j == 0 || !preamble_out_of_phase(tile, lane, w0)) return 0; // the retry would slice the same window again
+    if (j == 0 || !preamble_out_of_phase(tile, lane, w)) return 0; // the retry would slice the same window again
     return 2;
 }
 
-// Demodulate the candidate whose preamble starts at tile index w0 (sample j of the buffer).
+// Demodulate the candidate of window w (preamble at sample j of the buffer).
 //
 // Pass 1 is first attempted on float magnitude estimates: which half of a bit is larger is an exact comparison of s
 // (the magnitude is strictly increasing in s), "|lo-hi| >= 256" (:838) and the energy gate (:870-877) are decided from
 // the estimates whenever they are further from their thresholds than the estimate's error bound.  Only when some
 // decision is inside that margin -- or the retry slice, which rescales exact magnitudes, is needed -- are the exact
 // magnitudes computed.  Either way the bits that come out are exactly the reference's.
-__device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, const LaneTables& lt, Emit& e, int w0, uint32_t j, bool pass1_done)
+__device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, const LaneTables& lt, Emit& e, const Win& w, uint32_t j, bool pass1_done)
 {
     const bool has_b = lane < 48;
     // bit `lane` lives in samples j+16+2*lane, j+17+2*lane; bit 64+lane another 128 samples on (ADSB1090.cpp:831-835)
-    const int      ia  = w0 + 16 + 2 * lane;
-    const int      ib  = has_b ? ia + 128 : ia;
-    const uint32_t sLoA = tile[ia], sHiA = tile[ia + 1], sLoB = tile[ib], sHiB = tile[ib + 1];
+    uint32_t sLoA, sHiA, sLoB, sHiB;
+    load_bit_samples(tile, w, lane, has_b, sLoA, sHiA, sLoB, sHiB);
 
     // bit 0 with equal halves is the reference's only reachable "errors++" (:839-846); it survives the retry
     // unchanged (sample j+16 is never rescaled), so such a candidate can never be decoded.  m equal <=> s equal.
@@ -460,7 +508,7 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
         classify_and_emit(e, lane, lt, ba, bb, df, nbits, j, 0u, &stateless);
         if (stateless) return; // the reference accepts here and never retries
         // ---------------- pass 2: retry with phase correction (:814-826); identical to pass 1 unless the window is rescaled
-        if (j == 0 || !preamble_out_of_phase(tile, lane, w0)) return;
+        if (j == 0 || !preamble_out_of_phase(tile, lane, w)) return;
     }
     if (!have_exact)
     {
@@ -586,8 +634,9 @@ __device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWin
 #endif
 __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t tile[kTileU16];
+    __shared__ __attribute__((aligned(16))) uint32_t tile32[kTileDwords]; // the interleaved image of s (scan1090.h)
     __shared__ uint16_t                              queue[kQueueCap];
+    uint16_t* const                                  tile = reinterpret_cast<uint16_t*>(tile32);
 
     const int        lane = threadIdx.x;
     const LaneTables lt   = load_lane_tables(a.crc_tab, lane);
@@ -639,19 +688,25 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
 
     for (;;)
     {
-        // ---------------- s = (I-127)^2 + (Q-127)^2 for the window, parked in LDS
+        // ---------------- s = (I-127)^2 + (Q-127)^2 for the window, parked in LDS: row j (lower half) beside row j + 4 (upper half)
         wave_lds_fence(); // readers of the previous chunk are done
 #pragma unroll
-        for (int r = 0; r <= kRows; r++)
-        {
-            uint4 s;
-            s.x = iq2_to_s2(raw.row[r].x);
-            s.y = iq2_to_s2(raw.row[r].y);
-            s.z = iq2_to_s2(raw.row[r].z);
-            s.w = iq2_to_s2(raw.row[r].w);
-            if (r < kRows || lane < 32) *reinterpret_cast<uint4*>(&tile[kFront + r * kRowSamples + 8 * lane]) = s;
+        for (int j = 0; j <= kRows / 2; j++)
+        { // j = 4: the continuation -- row 4 again in the low halves, the halo row 8 in the high halves (lanes 0..31 hold it)
+            uint32_t    t[8];
+            const uint4 x = raw.row[j], y = raw.row[j + kRows / 2];
+            rows_to_s2(x.x, y.x, t[0], t[1]);
+            rows_to_s2(x.y, y.y, t[2], t[3]);
+            rows_to_s2(x.z, y.z, t[4], t[5]);
+            rows_to_s2(x.w, y.w, t[6], t[7]);
+            if (j < kRows / 2 || lane < kHalo / 8)
+            {
+                uint4* dst = reinterpret_cast<uint4*>(&tile32[j * kRowSamples + 8 * lane]);
+                dst[0]     = make_uint4(t[0], t[1], t[2], t[3]);
+                dst[1]     = make_uint4(t[4], t[5], t[6], t[7]);
+            }
         }
-        if (lane == 0) tile[kFront - 1] = (uint16_t)iq1_to_s(raw.front & 0xFFu, raw.front >> 8);
+        if (lane == 0) tile[kFrontSlot16] = (uint16_t)iq1_to_s(raw.front & 0xFFu, raw.front >> 8);
 
         // ---------------- prefetch: the next chunk's loads fly while this chunk is processed
         const ChunkGeom cur = g;
@@ -663,61 +718,58 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         }
         wave_lds_fence();
 
-        // ---------------- stage 1 on packed s.  A lane takes 16 consecutive positions (pairs (2i, 2i+1), i = 0..7) of a
-        // 1024-position super-row, so the 9-sample look-ahead is amortised over twice as many positions.
-        uint64_t surv = 0;
-#pragma unroll 1
-        for (int sr = 0; sr < kChunk / 1024; sr++)
+        // ---------------- stage 1 on the interleaved image: 512 dwords per pass, a lane takes dwords q = 8 lane .. 8 lane + 7 of
+        // them, i.e. eight positions q in the low halves and the eight positions q + 2048 in the high halves.  With
+        // s_a = sample q + a of either position the ten comparisons (ADSB1090.cpp:782-783) are
+        //     s0 > max(s1, s3, s4, s5, s6)    s2 > max(s1, s3)    s7 > s8    s9 > max(s6, s8)
+        // and max(s_a, s_a+2) is one shared array (used at a = 1, 4 and 6).
+        uint32_t surv32[2] = {0u, 0u};
+#pragma unroll
+        for (int b = 0; b < kHalfChunk / 512; b++)
         {
-            uint32_t    p0[13];
-            const int   w  = kFront + sr * 1024 + 16 * lane;
-            const uint4 q0 = *reinterpret_cast<const uint4*>(&tile[w]);
-            const uint4 q1 = *reinterpret_cast<const uint4*>(&tile[w + 8]);
-            const uint4 q2 = *reinterpret_cast<const uint4*>(&tile[w + 16]);
-            p0[0] = q0.x; p0[1] = q0.y; p0[2] = q0.z; p0[3] = q0.w;
-            p0[4] = q1.x; p0[5] = q1.y; p0[6] = q1.z; p0[7] = q1.w;
-            p0[8] = q2.x; p0[9] = q2.y; p0[10] = q2.z; p0[11] = q2.w;
-            p0[12] = *reinterpret_cast<const uint32_t*>(&tile[w + 24]);
-            uint32_t p1[12]; // odd-aligned pairs (s[2i+1], s[2i+2]), funnel-shifted out of p0.  (Reading them from LDS at a 2-byte
-                             // offset works on gfx950 but measured 3.7 % slower: misaligned ds_read_b128 is split.)
+            uint32_t        T[17];
+            const uint32_t* p  = &tile32[b * 512 + 8 * lane];
+            const uint4     q0 = *reinterpret_cast<const uint4*>(p), q1 = *reinterpret_cast<const uint4*>(p + 4);
+            const uint4     q2 = *reinterpret_cast<const uint4*>(p + 8), q3 = *reinterpret_cast<const uint4*>(p + 12);
+            T[0] = q0.x; T[1] = q0.y; T[2] = q0.z; T[3] = q0.w; T[4] = q1.x; T[5] = q1.y; T[6] = q1.z; T[7] = q1.w;
+            T[8] = q2.x; T[9] = q2.y; T[10] = q2.z; T[11] = q2.w; T[12] = q3.x; T[13] = q3.y; T[14] = q3.z; T[15] = q3.w;
+            T[16] = p[16];
+            uint32_t M2[14]; // (max(s_a, s_a+2)) of both positions
 #pragma unroll
-            for (int i = 0; i < 12; i++) p1[i] = __builtin_amdgcn_alignbit(p0[i + 1], p0[i], 16);
-            uint32_t m2o[10]; // (max(s[2i+1],s[2i+2]), max(s[2i+2],s[2i+3]))
-#pragma unroll
-            for (int i = 1; i <= 9; i++) m2o[i] = pk_max(p1[i], p0[i + 1]);
+            for (int a = 1; a <= 13; a++) M2[a] = pk_max(T[a], T[a + 2]);
             // Sign bit of each half of d1&d2&d3&d4 set <=> that position passes all ten comparisons.  Movemask by dot product:
-            // with the flags isolated at bits 15 and 31, dot2(flags, (2^(2i), 2^(2i+1))) adds 2^(15+2i) and 2^(16+2i), so
-            // the eight pairs accumulate into bits 15..30 of one register, one VALU op per pair.
+            // with the flags isolated at bits 15 and 31, dot2(flags, (2^k, 2^(k+8))) adds 2^(15+k) and 2^(23+k), so the eight
+            // dwords accumulate into bits 15..30 of one register, one VALU op per dword.
             uint32_t acc = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++)
+            for (int k = 0; k < 8; k++)
             {
-                // with j = 2i (low half) / 2i+1 (high half), m_k = s[j+k]:
-                const uint32_t mx36 = pk_max(m2o[i + 1], m2o[i + 2]);                  // max(m3..m6)
-                const uint32_t l0   = pk_max(p1[i], mx36);                             // max(m1, m3..m6)
-                const uint32_t d1   = pk_sub(l0, p0[i]);                               // < 0 : all of them < m0
-                const uint32_t d2   = pk_sub(pk_max(p1[i], p1[i + 1]), p0[i + 1]);     // max(m1,m3) < m2
-                const uint32_t d3   = pk_sub(p0[i + 4], pk_min(p1[i + 3], p1[i + 4])); // m8 < min(m7,m9)
-                const uint32_t d4   = pk_sub(p0[i + 3], p1[i + 4]);                    // m6 < m9
-                const uint32_t ok   = (d1 & d2 & d3 & d4) & 0x80008000u;
-                const u16x2    wt   = {(unsigned short)(1u << (2 * i)), (unsigned short)(2u << (2 * i))};
-                acc                 = __builtin_amdgcn_udot2(as_pk(ok), wt, acc, false);
+                const uint32_t l0 = pk_max(pk_max(M2[k + 4], T[k + 5]), M2[k + 1]); // max(s1, s3, s4, s5, s6)
+                const uint32_t d1 = pk_sub(l0, T[k]);                               // < 0 : all of them < s0
+                const uint32_t d2 = pk_sub(M2[k + 1], T[k + 2]);                    // max(s1, s3) < s2
+                const uint32_t d3 = pk_sub(T[k + 8], T[k + 7]);                     // s8 < s7
+                const uint32_t d4 = pk_sub(M2[k + 6], T[k + 9]);                    // max(s6, s8) < s9
+                const uint32_t ok = (d1 & d2 & d3 & d4) & 0x80008000u;
+                const u16x2    wt = {(unsigned short)(1u << k), (unsigned short)(256u << k)};
+                acc               = __builtin_amdgcn_udot2(as_pk(ok), wt, acc, false);
             }
+            // bit 8 h + i of the 16: position 2048 h + 512 b + 8 lane + i
             const uint32_t bits = acc >> 15;
-            surv |= (uint64_t)bits << (16 * sr);
+            if (b & 1) surv32[b >> 1] |= bits << 16;
+            else surv32[b >> 1] = bits;
         }
+        // bit n of surv: position 2048 ((n >> 3) & 1) + 512 (n >> 4) + 8 lane + (n & 7) of the chunk
+        uint64_t surv = (uint64_t)surv32[0] | ((uint64_t)surv32[1] << 32);
         if (cur.npos < (uint32_t)kChunk)
         { // last chunk of a buffer: positions at or beyond N-240 do not exist (ADSB1090.cpp:772)
-            const int base = 16 * lane;
 #pragma unroll
-            for (int sr = 0; sr < kChunk / 1024; sr++)
+            for (int n = 0; n < 64; n += 8)
             {
-                const int nvalid = (int)cur.npos - (sr * 1024 + base);
-                uint64_t  keep   = (nvalid >= 16) ? 0xFFFFull : (nvalid <= 0 ? 0ull : ((1ull << nvalid) - 1ull));
-                surv &= ~(0xFFFFull << (16 * sr)) | (keep << (16 * sr));
+                const int nvalid = (int)cur.npos - (kHalfChunk * ((n >> 3) & 1) + 512 * (n >> 4) + 8 * lane);
+                uint64_t  keep   = (nvalid >= 8) ? 0xFFull : (nvalid <= 0 ? 0ull : ((1ull << nvalid) - 1ull));
+                surv &= ~(0xFFull << n) | (keep << n);
             }
         }
-
 
         // ---------------- survivors -> queue -> stage 2 -> demod, at most kQueueCap survivors per pass
         const uint32_t mine = (uint32_t)__builtin_popcountll(surv);
@@ -736,7 +788,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
                 {
                     const int b = __builtin_ctzll(sv);
                     sv &= sv - 1;
-                    if (idx - base < (uint32_t)kQueueCap) queue[idx - base] = (uint16_t)((b >> 4) * 1024 + 16 * lane + (b & 15));
+                    if (idx - base < (uint32_t)kQueueCap) queue[idx - base] = (uint16_t)(kHalfChunk * ((b >> 3) & 1) + 512 * (b >> 4) + 8 * lane + (b & 7));
                     idx++;
                 }
             }
@@ -755,14 +807,14 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
                     // high = (m0+m2+m7+m9)/6 needs four exact magnitudes; "m_x < high" for the six quiet samples is then
                     // one test on the largest of their s values: m(s) <= high-1  <=>  129600*s <= high^2 - high.
                     pos                 = queue[idx];
-                    const int      w    = kFront + (int)pos;
-                    uint32_t       sq   = tile[w + 4];
-                    sq = (tile[w + 5] > sq) ? tile[w + 5] : sq;
-                    sq = (tile[w + 11] > sq) ? tile[w + 11] : sq;
-                    sq = (tile[w + 12] > sq) ? tile[w + 12] : sq;
-                    sq = (tile[w + 13] > sq) ? tile[w + 13] : sq;
-                    sq = (tile[w + 14] > sq) ? tile[w + 14] : sq;
-                    const uint32_t s0 = tile[w], s2 = tile[w + 2], s7 = tile[w + 7], s9 = tile[w + 9];
+                    const uint16_t* w   = &tile[tile_index(pos)]; // sample a of this position: w[2 a]
+                    uint32_t       sq   = w[2 * 4];
+                    sq = (w[2 * 5] > sq) ? w[2 * 5] : sq;
+                    sq = (w[2 * 11] > sq) ? w[2 * 11] : sq;
+                    sq = (w[2 * 12] > sq) ? w[2 * 12] : sq;
+                    sq = (w[2 * 13] > sq) ? w[2 * 13] : sq;
+                    sq = (w[2 * 14] > sq) ? w[2 * 14] : sq;
+                    const uint32_t s0 = w[0], s2 = w[2 * 2], s7 = w[2 * 7], s9 = w[2 * 9];
                     // First on estimates: every magnitude estimate is within kEstErr of the reference's integer, so the sum of
                     // four is within 4 kEstErr and high = sum / 6 (truncating) lies in [(sum - 5) / 6, sum / 6].
                     //   surely quiet  : e(max) + kEstErr <= (sum_est - 4 kEstErr - 5) / 6 - 1
@@ -780,14 +832,14 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
                     ok = false;
                     if (idx < nq)
                     {
-                        const int      w    = kFront + (int)pos;
-                        const uint32_t high = (uint32_t)(mag_of_s(tile[w]) + mag_of_s(tile[w + 2]) + mag_of_s(tile[w + 7]) + mag_of_s(tile[w + 9])) / 6u;
-                        uint32_t       sq   = tile[w + 4];
-                        sq = (tile[w + 5] > sq) ? tile[w + 5] : sq;
-                        sq = (tile[w + 11] > sq) ? tile[w + 11] : sq;
-                        sq = (tile[w + 12] > sq) ? tile[w + 12] : sq;
-                        sq = (tile[w + 13] > sq) ? tile[w + 13] : sq;
-                        sq = (tile[w + 14] > sq) ? tile[w + 14] : sq;
+                        const uint16_t* w   = &tile[tile_index(pos)];
+                        const uint32_t high = (uint32_t)(mag_of_s(w[0]) + mag_of_s(w[2 * 2]) + mag_of_s(w[2 * 7]) + mag_of_s(w[2 * 9])) / 6u;
+                        uint32_t       sq   = w[2 * 4];
+                        sq = (w[2 * 5] > sq) ? w[2 * 5] : sq;
+                        sq = (w[2 * 11] > sq) ? w[2 * 11] : sq;
+                        sq = (w[2 * 12] > sq) ? w[2 * 12] : sq;
+                        sq = (w[2 * 13] > sq) ? w[2 * 13] : sq;
+                        sq = (w[2 * 14] > sq) ? w[2 * 14] : sq;
                         const uint32_t se = sq + ((sq + 1u) >> 15);
                         ok = high != 0 && (uint32_t)__umul24(se, 129600u) <= high * high - high;
                     }
@@ -802,8 +854,9 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
             for (uint32_t t = 0; t < n2; t++)
             {
                 const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)queue[t]);
-                const int todo = demod_strong_frame(tile, lane, lt, e, kFront + (int)pos, cur.g0 + pos);
-                if (todo) demod_candidate(tile, lane, lt, e, kFront + (int)pos, cur.g0 + pos, todo == 2);
+                const Win      w   = make_win(pos);
+                const int      todo = demod_strong_frame(tile, lane, lt, e, w, cur.g0 + pos);
+                if (todo) demod_candidate(tile, lane, lt, e, w, cur.g0 + pos, todo == 2);
             }
             wave_lds_fence();
         }
