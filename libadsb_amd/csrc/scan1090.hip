@@ -40,7 +40,9 @@ namespace adsb_amd
 namespace
 {
 
-constexpr int kQueueCap = 256; // stage-1 survivors processed per pass (a chunk rarely has more than ~60)
+constexpr int kQueueCap  = 256;                               // stage-1 survivors processed per pass (a chunk rarely has more than ~60)
+constexpr int kLdsDwords = kTileDwords + kQueueCap / 2 + 12;   // 2448 dwords = 9792 bytes per wave (16 waves per CU fit in 160 KiB)
+static_assert(2 * kLdsDwords > (2 * (kHalfChunk - 1) + 1) + 32 + 4 * 63 + 258, "reads of the fast demodulation path must stay inside the array");
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short          i16x2 __attribute__((ext_vector_type(2)));
@@ -67,25 +69,30 @@ __device__ __forceinline__ uint32_t iq2_to_s2(uint32_t x)
     return r;
 }
 
-// (I_a, I_b) and (Q_a, Q_b) as zero-extended 16-bit pairs -> (s_a | s_b << 16), same arithmetic as iq2_to_s2
-__device__ __forceinline__ uint32_t pair_to_s2(uint32_t i16, uint32_t q16)
+// (127 - I) and (127 - Q) of two samples as sign-extended 16-bit pairs -> (s_a | s_b << 16), s saturated to 32767 as in iq2_to_s2
+__device__ __forceinline__ uint32_t pair_to_s2(uint32_t di, uint32_t dq)
 {
-    const u16x2    c  = {127, 127};
-    const uint32_t di = as_u32(as_pk(i16) - c), dq = as_u32(as_pk(q16) - c);
-    const uint32_t a  = as_u32(as_pk(di) * as_pk(di));
+    const uint32_t a = as_u32(as_pk(di) * as_pk(di)); // (127-I)^2 <= 16384, exact modulo 2^16
     uint32_t       r;
     asm("v_pk_mad_i16 %0, %1, %1, %2 clamp" : "=v"(r) : "v"(dq), "v"(a));
     return r;
 }
 
 // The same 4 bytes (two samples) of two rows, x from the lower half of the chunk and y from the upper -> two dwords of the image:
-// t0 = (s(x sample 0), s(y sample 0)), t1 = (s(x sample 1), s(y sample 1)).  v_perm_b32 picks one byte from each source
-// (selector 0..3 = bytes of the second operand, 4..7 = bytes of the first, 0x0C = zero), so pairing two rows costs the same six
-// operations per dword as unpacking two neighbouring samples.
+// t0 = (s(x sample 0), s(y sample 0)), t1 = (s(x sample 1), s(y sample 1)).
+// Byte ^ 0x7F is 127 - byte as a signed 8-bit number, for every byte value (127 - 255 = -128 included), so one XOR removes the
+// offset of all four bytes of a register and squaring does not care about the sign.  v_perm_b32 then builds the 16-bit pairs:
+// selector 0..3 = bytes of the second operand, 4..7 = bytes of the first, and 8 / 9 / 10 / 11 replicate the sign bit of byte
+// 1 / 3 / 5 / 7, i.e. it sign-extends the odd bytes (Q) directly; for the even bytes (I) the registers are first shifted up
+// by one byte.  Per dword of the image: 4 half-rate operations (two permutes, multiply, multiply-add) and 2 full-rate ones
+// (the XOR and the shift are shared by the two dwords a register pair yields), where unpack + subtract + square took 6
+// half-rate ones.
 __device__ __forceinline__ void rows_to_s2(uint32_t x, uint32_t y, uint32_t& t0, uint32_t& t1)
 {
-    t0 = pair_to_s2(__builtin_amdgcn_perm(y, x, 0x0C040C00u), __builtin_amdgcn_perm(y, x, 0x0C050C01u));
-    t1 = pair_to_s2(__builtin_amdgcn_perm(y, x, 0x0C060C02u), __builtin_amdgcn_perm(y, x, 0x0C070C03u));
+    const uint32_t zx = x ^ 0x7F7F7F7Fu, zy = y ^ 0x7F7F7F7Fu;
+    const uint32_t ux = zx << 8, uy = zy << 8;
+    t0 = pair_to_s2(__builtin_amdgcn_perm(uy, ux, 0x0A050801u), __builtin_amdgcn_perm(zy, zx, 0x0A050801u));
+    t1 = pair_to_s2(__builtin_amdgcn_perm(uy, ux, 0x0B070903u), __builtin_amdgcn_perm(zy, zx, 0x0B070903u));
 }
 
 __device__ __forceinline__ uint32_t iq1_to_s(uint32_t i, uint32_t q)
@@ -376,52 +383,70 @@ __device__ __forceinline__ bool preamble_out_of_phase(const uint16_t* tile, int 
     return (3 * m3 > m2) || (3 * m10 > m9) || (3 * m6 > m7) || (3 * m_1 > m1);
 }
 
-// The common case, nearly straight-line: a frame whose every relevant bit is far above the "decided" and energy
-// thresholds.  Then the sliced bits are simply "which half is larger" (an exact comparison of s) and pass 1 is settled
-// here: DF11/17 with good parity or a single repairable bit is accepted by the reference on the spot; an AP-type DF
-// yields its conditional record and, unless the preamble is out of phase, the retry would reproduce the same bits.
+// The common cases, nearly straight-line and in integer arithmetic on s only.
+//
+// (1) A frame whose every relevant bit is far above the "decided" and energy thresholds.  A bit is called strong when the larger
+//     of its two samples has L >= 2 S + 108 against the smaller one: then sqrt(L) - sqrt(S) >= sqrt(2 S + 108) - sqrt(S) >= 7.348
+//     (minimum at S = 54), so the reference's magnitudes differ by at least 360 * 7.348 - 1 = 2644, far above 256 (the bit is
+//     decided, :838) and above 2550 (if every bit of the frame is strong the energy average passes, :870-877).  The sliced bits
+//     are then simply "which half is larger" (an exact comparison of s) and pass 1 is settled here: DF11/17 with good parity or a
+//     single repairable bit is accepted by the reference on the spot; an AP-type DF yields its conditional record and, unless
+//     the preamble is out of phase, the retry would reproduce the same bits.
+// (2) Noise that got through the preamble gates (40 % of the candidates of a quiet band).  |lo - hi| <= max(lo, hi) =
+//     round(360 sqrt(max s)) <= 360 sqrt(max s) + 1/2, and by Cauchy-Schwarz sum_b sqrt(x_b) <= sqrt(n sum_b x_b); so with
+//     S_n = sum over the first n bits of max(s_lo, s_hi):  sum |lo - hi| <= 360 sqrt(n S_n) + n/2.  The gate needs
+//     sum |lo - hi| >= 1275 n (:870-877 with msglen * 4 = n / 2), impossible once S_n < n (1274.5 / 360)^2 = 12.5336 n, i.e.
+//     S_56 <= 701 resp. S_112 <= 1403.  If that holds for BOTH lengths the candidate is dead whichever DF its bits spell, on
+//     both passes (the retry restores the window before the gate, :855-856).
 // Returns 0 when the candidate is finished, 1 when the general demodulator has to run from scratch (nothing was
 // emitted), 2 when only its retry pass remains (the pass-1 record is already out).
 __device__ __forceinline__ int demod_strong_frame(const uint16_t* tile, int lane, const LaneTables& lt, Emit& e, const Win& w, uint32_t j)
 {
-    const bool has_b = lane < 48;
-    uint32_t   sLoA, sHiA, sLoB, sHiB;
-    load_bit_samples(tile, w, lane, has_b, sLoA, sHiA, sLoB, sHiB);
-    if (__builtin_amdgcn_readfirstlane((int)(sLoA == sHiA))) return 0; // :839-846, dead on both passes
-    const float    fA = __builtin_fabsf(mag_estimate(sLoA) - mag_estimate(sHiA));
-    const float    fB = __builtin_fabsf(mag_estimate(sLoB) - mag_estimate(sHiB));
-    const uint64_t strongA = ballot(fA >= 2560.0f), strongB = ballot(has_b && fB >= 2560.0f);
-    const uint64_t valA = ballot(sLoA > sHiA), valB = ballot(has_b && sLoB > sHiB);
-    const uint32_t df   = (uint32_t)(__builtin_bitreverse64(valA) >> 59);
-    // everything below is selected, not branched, on the (wave-uniform) frame length
+    // bit `lane` and bit 64 + lane; lanes >= 48 have no second bit: they read whatever follows in LDS (the array is long enough)
+    // and every use of their B values is masked
+    const uint32_t ia   = w.a0 + 32u + 4u * (uint32_t)lane;
+    const uint32_t sLoA = tile[ia], sHiA = tile[ia + 2], sLoB = tile[ia + 256], sHiB = tile[ia + 258];
+    const bool     bitA = sLoA > sHiA, bitB = sLoB > sHiB;
+    const uint64_t valA = ballot(bitA), valB = ballot(bitB) & kMask48;
+    const uint64_t strongA = ballot(sLoA >= 2u * sHiA + 108u) | ballot(sHiA >= 2u * sLoA + 108u);
+    const uint64_t strongB = ballot(sLoB >= 2u * sHiB + 108u) | ballot(sHiB >= 2u * sLoB + 108u);
+    const uint32_t df      = (uint32_t)(__builtin_bitreverse64(valA) >> 59);
     const bool     is_long = df_is_long(df);
     const bool     is17    = (df == 17 || df == 11);
-    const uint64_t ba      = is_long ? valA : (valA & kMask56);
-    const uint64_t bb      = is_long ? valB : 0ull;
-    const bool     strong  = is_long ? (strongA == ~0ull && strongB == kMask48) : ((strongA & kMask56) == kMask56);
+    const bool     strong  = is_long ? (strongA == ~0ull && (strongB & kMask48) == kMask48) : ((strongA & kMask56) == kMask56);
     if (!strong || !(is17 || df_is_ap(df)))
     {
-        // Not a strong frame.  Most such candidates are noise that got through the preamble gates; their energy average
-        // (:870-881) is below the gate whichever length the sliced DF bits would select, and the retry does not change that
-        // (the window is restored before the gate, :855-856).  Each |lo-hi| estimate is within 2*kEstErr + 0.5 of the true
-        // integer, so are the averages: 5 below the gate on both is certain.
-        const uint32_t iA = (uint32_t)(fA + 0.5f), iB = has_b ? (uint32_t)(fB + 0.5f) : 0u;
-        const uint32_t e56 = wave_sum(lane < 56 ? iA : 0u), erest = wave_sum((lane >= 56 ? iA : 0u) + iB);
-        if (e56 / 28u + 5u < 2550u && (e56 + erest) / 56u + 5u < 2550u) return 0;
+        const uint32_t mxA = sLoA > sHiA ? sLoA : sHiA, mxB = lane < 48 ? (sLoB > sHiB ? sLoB : sHiB) : 0u;
+        if (ballot((mxA | mxB) > 701u) == 0)
+        { // every term is small, so the two sums fit the two halves of one register: one reduction instead of two
+            const uint32_t sum  = wave_sum((lane < 56 ? mxA : (mxA << 16)) + (mxB << 16));
+            const uint32_t s56  = sum & 0xFFFFu, s112 = s56 + (sum >> 16);
+            if (s56 <= 701u && s112 <= 1403u) return 0;
+        }
         return 1;
     }
-    const uint32_t nbits   = is_long ? 112u : 56u;
-    const uint32_t tab_a   = is_long ? lt.crc_a : lt.crc_s; // crc_s is 0 on lanes >= 56
-    const uint32_t contrib = (((ba >> lane) & 1ull) ? tab_a : 0u) ^ ((has_b && ((bb >> lane) & 1ull)) ? lt.crc_b : 0u);
-    const uint32_t stored  = is_long ? ((uint32_t)(__builtin_bitreverse64(bb) >> 16) & 0xFFFFFFu) : ((uint32_t)(__builtin_bitreverse64(ba) >> 8) & 0xFFFFFFu);
-    const uint32_t syn     = wave_xor(contrib) ^ stored;
+    const uint64_t ba = is_long ? valA : (valA & kMask56);
+    const uint64_t bb = is_long ? valB : 0ull;
+    const uint32_t nbits = is_long ? 112u : 56u;
+    uint32_t       contrib, stored;
+    if (is_long)
+    { // crc_b is 0 on lanes >= 48
+        contrib = (bitA ? lt.crc_a : 0u) ^ (bitB ? lt.crc_b : 0u);
+        stored  = (uint32_t)(__builtin_bitreverse64(bb) >> 16) & 0xFFFFFFu;
+    }
+    else
+    { // crc_s is 0 on lanes >= 56
+        contrib = bitA ? lt.crc_s : 0u;
+        stored  = (uint32_t)(__builtin_bitreverse64(ba) >> 8) & 0xFFFFFFu;
+    }
+    const uint32_t syn = wave_xor(contrib) ^ stored;
     if (is17)
     {
         int errorbit = -1;
         if (syn != 0)
         { // FixSingleBitErrors (:304-332): first bit whose flip makes stored == computed
             const uint64_t ma = is_long ? ballot(syn == lt.syn_a) : ballot(lane < 56 && syn == lt.syn_s);
-            const uint64_t mb = is_long ? ballot(has_b && syn == lt.syn_b) : 0ull;
+            const uint64_t mb = is_long ? ballot(lane < 48 && syn == lt.syn_b) : 0ull;
             if (ma) errorbit = __builtin_ctzll(ma);
             else if (mb) errorbit = 64 + __builtin_ctzll(mb);
             else return 1; // not repairable: the reference retries with phase correction
@@ -634,9 +659,12 @@ __device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWin
 #endif
 __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t tile32[kTileDwords]; // the interleaved image of s (scan1090.h)
-    __shared__ uint16_t                              queue[kQueueCap];
-    uint16_t* const                                  tile = reinterpret_cast<uint16_t*>(tile32);
+    // the interleaved image of s (scan1090.h), the slot of the sample in front of the chunk, then the survivor queue.  The queue
+    // doubles as the landing zone of the fast demodulation path's reads beyond a window (lanes 48..63 have no second bit; what
+    // they fetch is never used): the last window starts at half 4095 and those reads reach half 4895 < 2 * kLdsDwords.
+    __shared__ __attribute__((aligned(16))) uint32_t tile32[kLdsDwords];
+    uint16_t* const                                  tile  = reinterpret_cast<uint16_t*>(tile32);
+    uint16_t* const                                  queue = reinterpret_cast<uint16_t*>(&tile32[kTileDwords]);
 
     const int        lane = threadIdx.x;
     const LaneTables lt   = load_lane_tables(a.crc_tab, lane);
