@@ -71,6 +71,20 @@ typedef struct adsb_amd_record
                           and never reads it) */
 } adsb_amd_record_t;
 
+/*
+ * The stateless fields of DecodeModesMessage (ADSB1090.cpp:530-672) for one record, computed by the GPU in the ordering pass:
+ * what the aircraft update (InteractiveReceiveData, :1124-1175) consumes.  kind: 0 nothing to update, 1 altitude (DF0/4/20, AC13),
+ * 2 identification (a, b = the eight callsign characters, first character in the lowest byte of a), 3 airborne position
+ * (altitude from AC12, a = raw CPR latitude, b = raw CPR longitude, odd = CPR format flag), 4 airborne velocity (a = speed,
+ * b = track in whole degrees, the reference's truncation and wrap).  Parallel to the record array.
+ */
+typedef struct adsb_amd_decoded
+{
+    uint8_t  kind, metype, mesub, odd;
+    int32_t  altitude;
+    uint32_t a, b;
+} adsb_amd_decoded_t;
+
 /* Accepted frame + aircraft snapshot handed to the callback (mirrors what IListener::OnChanged sees). */
 typedef struct adsb_amd_frame
 {
@@ -130,6 +144,9 @@ int adsb_amd_scan_1090_submit(adsb_amd_ctx_t* ctx, const void* iq_device, size_t
                               void* hip_stream, int slot);
 /* Waits for the slot; *records points into context-owned pinned memory, valid until the next submit on that slot. */
 int adsb_amd_scan_1090_fetch(adsb_amd_ctx_t* ctx, int slot, const adsb_amd_record_t** records, size_t* n);
+/* fetch plus the decoded fields of every record (same order, same lifetime as the record pointer). */
+int adsb_amd_scan_1090_fetch_decoded(adsb_amd_ctx_t* ctx, int slot, const adsb_amd_record_t** records, const adsb_amd_decoded_t** decoded,
+                                     size_t* n);
 /* The same wait, but the sorted records are copied device-to-device into `dst_device` (room for `cap` records, same GPU) on
  * `hip_stream` (NULL: an internal stream, and the call returns after the copy has completed): for consumers that stay on the
  * GPU, e.g. the RCCL gather of the sharded recorded-file case.  ADSB_AMD_ENOSPC when cap is too
@@ -140,6 +157,10 @@ int adsb_amd_scan_1090_timing(adsb_amd_ctx_t* ctx, int slot, float* scan_kernel_
 
 /* Parity helper: magnitudes exactly as ADSB1090.cpp:165-173 computes them (n = nbytes/2 values). */
 int adsb_amd_magnitude_1090(adsb_amd_ctx_t* ctx, const uint8_t* iq_host, size_t nbytes, uint16_t* mag_out);
+/* Parity helpers: the field decoder of the ordering pass run on the device over arbitrary records (only msg and df are read),
+ * and the host build of the same function (one record; needs no GPU). */
+int  adsb_amd_decode_1090(adsb_amd_ctx_t* ctx, const adsb_amd_record_t* records_host, size_t n, adsb_amd_decoded_t* out_host);
+void adsb_amd_decode_record_host(const adsb_amd_record_t* record, adsb_amd_decoded_t* out);
 
 /* ---------------------------------------------------------------- host half */
 /* The order-dependent rest of ADSB1090Handler: skip-ahead and retry order (ADSB1090.cpp:886-957), ICAO cache and BruteForceAp
@@ -158,7 +179,14 @@ void adsb_amd_resolver_set_sample_clock(adsb_amd_resolver_t* r, int64_t t0_ns, u
  */
 long adsb_amd_resolver_feed(adsb_amd_resolver_t* r, const adsb_amd_record_t* records, size_t n, size_t samples_per_buffer,
                             size_t nbuffers, adsb_amd_on_changed_fn cb, void* user);
+/* The same with the GPU's decoded fields (adsb_amd_scan_1090_fetch_decoded): the host does no field decoding at all. */
+long adsb_amd_resolver_feed_decoded(adsb_amd_resolver_t* r, const adsb_amd_record_t* records, const adsb_amd_decoded_t* decoded, size_t n,
+                                    size_t samples_per_buffer, size_t nbuffers, adsb_amd_on_changed_fn cb, void* user);
 size_t adsb_amd_resolver_aircraft_count(const adsb_amd_resolver_t* r);
+/* Parity helpers (host only): CprNlFunction (ADSB1090.cpp:993-1055) and the global airborne decode (:1079-1121) as the resolver
+ * computes them; adsb_amd_cpr_global returns 0 when the two latitudes fall into different zones (state untouched). */
+int adsb_amd_cpr_nl(double lat);
+int adsb_amd_cpr_global(double even_lat, double even_lon, double odd_lat, double odd_lon, int use_even, int32_t* lat1e7, int32_t* lon1e7);
 /* An adsb_amd_on_changed_fn that only counts: *(uint64_t*)user += 1 per call (IListener::OnChanged stand-in for rate runs). */
 void adsb_amd_count_callback(void* user, const adsb_amd_frame_t* frame, const adsb_amd_aircraft_t* aircraft);
 

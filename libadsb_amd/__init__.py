@@ -21,13 +21,16 @@ FRAME_DTYPE = np.dtype([("offset", "<u8"), ("msg", "u1", (14,)), ("nbits", "u1")
                         ("phase_applied", "u1"), ("df", "u1"), ("reserved", "u1"), ("addr", "<u4")])
 AIRCRAFT_DTYPE = np.dtype([("addr", "<u4"), ("callsign", "S8"), ("lat1e7", "<i4"), ("lon1e7", "<i4"), ("altitude", "<i4"),
                            ("speed", "<u4"), ("track", "<u4"), ("vert_rate", "<i4"), ("squawk", "<u4")])
-assert RECORD_DTYPE.itemsize == 32 and FRAME_DTYPE.itemsize == 32 and AIRCRAFT_DTYPE.itemsize == 40
+DECODED_DTYPE = np.dtype([("kind", "u1"), ("metype", "u1"), ("mesub", "u1"), ("odd", "u1"), ("altitude", "<i4"), ("a", "<u4"), ("b", "<u4")])
+K_NONE, K_ALTITUDE, K_IDENT, K_POSITION, K_VELOCITY = range(5)
+assert RECORD_DTYPE.itemsize == 32 and FRAME_DTYPE.itemsize == 32 and AIRCRAFT_DTYPE.itemsize == 40 and DECODED_DTYPE.itemsize == 16
 
 ON_CHANGED = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
 
 EXPORTS = [
     "adsb_amd_version", "adsb_amd_create", "adsb_amd_destroy", "adsb_amd_last_error", "adsb_amd_scan_1090",
-    "adsb_amd_scan_1090_submit", "adsb_amd_scan_1090_fetch", "adsb_amd_scan_1090_fetch_device", "adsb_amd_scan_1090_timing", "adsb_amd_magnitude_1090",
+    "adsb_amd_scan_1090_submit", "adsb_amd_scan_1090_fetch", "adsb_amd_scan_1090_fetch_decoded", "adsb_amd_scan_1090_fetch_device", "adsb_amd_scan_1090_timing", "adsb_amd_magnitude_1090",
+    "adsb_amd_decode_1090", "adsb_amd_decode_record_host", "adsb_amd_resolver_feed_decoded", "adsb_amd_cpr_nl", "adsb_amd_cpr_global",
     "adsb_amd_resolver_create", "adsb_amd_resolver_destroy", "adsb_amd_resolver_set_sample_clock", "adsb_amd_resolver_feed",
     "adsb_amd_resolver_aircraft_count", "adsb_amd_count_callback", "adsb_amd_handler_create", "adsb_amd_handler_destroy", "adsb_amd_handler_last_error",
     "adsb_amd_handler_set_sample_clock", "adsb_amd_handler_handle_data", "adsb_amd_handler_replay_file", "adsb_amd_host_alloc", "adsb_amd_host_free",
@@ -65,6 +68,14 @@ def lib():
         L.adsb_amd_scan_1090.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.adsb_amd_scan_1090_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
         L.adsb_amd_scan_1090_fetch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.adsb_amd_scan_1090_fetch_decoded.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.adsb_amd_decode_1090.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.adsb_amd_decode_record_host.argtypes = [C.c_void_p, C.c_void_p]
+        L.adsb_amd_decode_record_host.restype = None
+        L.adsb_amd_cpr_nl.argtypes = [C.c_double]
+        L.adsb_amd_cpr_global.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.adsb_amd_resolver_feed_decoded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.adsb_amd_resolver_feed_decoded.restype = C.c_long
         L.adsb_amd_scan_1090_fetch_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
         L.adsb_amd_scan_1090_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.adsb_amd_magnitude_1090.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -175,6 +186,23 @@ class Scanner:
         arr = np.frombuffer(buf, dtype=RECORD_DTYPE)
         return arr.copy() if copy else arr
 
+    def fetch_decoded(self, slot=0, copy=True):
+        """fetch plus the GPU-decoded fields of every record: (records, decoded), parallel arrays."""
+        p, q, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        self._check(self._l.adsb_amd_scan_1090_fetch_decoded(self._h, slot, C.byref(p), C.byref(q), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, RECORD_DTYPE), np.zeros(0, DECODED_DTYPE)
+        rec = np.frombuffer((C.c_uint8 * (n.value * 32)).from_address(p.value), dtype=RECORD_DTYPE)
+        dec = np.frombuffer((C.c_uint8 * (n.value * 16)).from_address(q.value), dtype=DECODED_DTYPE)
+        return (rec.copy(), dec.copy()) if copy else (rec, dec)
+
+    def decode(self, records):
+        """The ordering pass's field decoder run on the device over arbitrary records (parity helper)."""
+        records = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+        out = np.zeros(len(records), dtype=DECODED_DTYPE)
+        self._check(self._l.adsb_amd_decode_1090(self._h, records.ctypes.data, len(records), out.ctypes.data))
+        return out
+
     def fetch_device(self, slot, dst_ptr, cap_records, stream=0):
         """Waits for the slot and copies its records device-to-device to `dst_ptr` (enqueued on `stream`); returns the count."""
         n = C.c_size_t()
@@ -209,16 +237,22 @@ class Resolver:
     def __del__(self):
         self.close()
 
-    def feed(self, records, samples_per_buffer, nbuffers, collect=True, count_callbacks=False):
+    def feed(self, records, samples_per_buffer, nbuffers, collect=True, count_callbacks=False, decoded=None):
         """collect: gather every callback's frame + aircraft snapshot (Python trampoline, slow); count_callbacks: fire the
-        library's own counting listener instead (the callback path at native speed); neither: no callback at all."""
+        library's own counting listener instead (the callback path at native speed); neither: no callback at all.
+        decoded: the GPU's decoded fields for these records (Scanner.fetch_decoded); None: the host decodes."""
         records = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
         col = _Collector()
         cb, user = (C.cast(col.cb, C.c_void_p), None) if collect else (None, None)
         counter = C.c_uint64(0)
         if count_callbacks and not collect:
             cb, user = C.cast(self._l.adsb_amd_count_callback, C.c_void_p), C.cast(C.pointer(counter), C.c_void_p)
-        n = self._l.adsb_amd_resolver_feed(self._h, records.ctypes.data, records.size, samples_per_buffer, nbuffers, cb, user)
+        if decoded is not None:
+            decoded = np.ascontiguousarray(decoded, dtype=DECODED_DTYPE)
+            assert len(decoded) == len(records)
+            n = self._l.adsb_amd_resolver_feed_decoded(self._h, records.ctypes.data, decoded.ctypes.data, records.size, samples_per_buffer, nbuffers, cb, user)
+        else:
+            n = self._l.adsb_amd_resolver_feed(self._h, records.ctypes.data, records.size, samples_per_buffer, nbuffers, cb, user)
         if count_callbacks and not collect and n >= 0:
             assert counter.value == n, "one callback per accepted frame"
         if n < 0:
@@ -302,6 +336,16 @@ class PinnedBuffer:
 
 UAT_FRAME = C.CFUNCTYPE(None, C.c_void_p, C.c_char, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_uint64)
 DUMP_RAW_MESSAGE = C.CFUNCTYPE(None, C.c_char, C.POINTER(C.c_uint8), C.c_int, C.c_int)
+
+
+def decode_records_host(records):
+    """Host build of the field decoder (decode1090.h), record by record.  Needs no GPU."""
+    records = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+    out = np.zeros(len(records), dtype=DECODED_DTYPE)
+    L = lib()
+    for i in range(len(records)):
+        L.adsb_amd_decode_record_host(records.ctypes.data + 32 * i, out.ctypes.data + 16 * i)
+    return out
 
 
 def rs_decode978(kind, codeword):

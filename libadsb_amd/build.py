@@ -32,7 +32,9 @@ def build_hip(force=False, verbose=False):
     if not force and not _stale(LIB, HIP_DEPS):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared", "-Wall", "-Wextra",
+    # host side: x86-64-v3 (AVX2/FMA class: inline floor/round) with contraction off, so that the double arithmetic of the CPR and
+    # field decoding rounds exactly like the expressions as written (the oracle is built the same way)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared", "-Wall", "-Wextra", "-march=x86-64-v3", "-ffp-contract=off",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in HIP_SOURCES]
     if verbose:
         print(" ".join(cmd))

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "adsb_amd.h"
+#include "decode1090.h"
 #include "resolver1090.hpp"
 #include "scan1090.h"
 
@@ -34,10 +35,13 @@ struct Slot
     uint32_t*          block_sums = nullptr; // one per 256 chunks
     adsb_amd_record_t* regions  = nullptr; // total_chunks * cap
     adsb_amd_record_t* dense    = nullptr;
+    adsb_amd_decoded_t* decoded = nullptr; // parallel to dense
     uint32_t*          total_d  = nullptr; // device {total, overflow}
     uint32_t*          work_d   = nullptr; // device: one chunk counter per XCD (scan1090_kernel), zero between scans
     uint32_t*          total_h  = nullptr; // pinned {total, overflow}
     adsb_amd_record_t* host     = nullptr; // pinned result
+    adsb_amd_decoded_t* host_dec = nullptr; // pinned, parallel to host (same capacity)
+    bool               dec_valid = false;  // host_dec holds the last fetch's decoded fields
     size_t             host_cap = 0;       // records
     size_t             chunks_cap = 0, cap_per_chunk = 0;
     hipEvent_t         ev_begin = nullptr, ev_scan0 = nullptr, ev_scan1 = nullptr, ev_done = nullptr;
@@ -90,8 +94,10 @@ void free_slot(Slot& s)
     if (s.block_sums) (void)hipFree(s.block_sums);
     if (s.regions) (void)hipFree(s.regions);
     if (s.dense) (void)hipFree(s.dense);
+    if (s.decoded) (void)hipFree(s.decoded);
     s.counts = s.block_sums = nullptr;
     s.regions = s.dense = nullptr;
+    s.decoded = nullptr;
     s.chunks_cap = s.cap_per_chunk = 0;
 }
 
@@ -104,6 +110,7 @@ int ensure_slot(adsb_amd_ctx* c, Slot& s, size_t chunks, size_t cap)
     HIP_TRY(c, hipMalloc(&s.block_sums, ((nch + 255) / 256) * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc(&s.regions, nch * cap * sizeof(adsb_amd_record_t)));
     HIP_TRY(c, hipMalloc(&s.dense, nch * cap * sizeof(adsb_amd_record_t)));
+    HIP_TRY(c, hipMalloc(&s.decoded, nch * cap * sizeof(adsb_amd_decoded_t)));
     s.chunks_cap    = nch;
     s.cap_per_chunk = cap;
     return ADSB_AMD_OK;
@@ -113,10 +120,13 @@ int ensure_host(adsb_amd_ctx* c, Slot& s, size_t nrec)
 {
     if (nrec <= s.host_cap) return ADSB_AMD_OK;
     if (s.host) (void)hipHostFree(s.host);
+    if (s.host_dec) (void)hipHostFree(s.host_dec);
     s.host      = nullptr;
+    s.host_dec  = nullptr;
     s.host_cap  = 0;
     size_t want = nrec + nrec / 4 + 1024;
     HIP_TRY(c, hipHostMalloc(&s.host, want * sizeof(adsb_amd_record_t), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc(&s.host_dec, want * sizeof(adsb_amd_decoded_t), hipHostMallocDefault));
     s.host_cap = want;
     return ADSB_AMD_OK;
 }
@@ -161,7 +171,7 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     HIP_TRY(c, hipEventRecord(s.ev_scan0, s.stream));
     HIP_TRY(c, launch_scan1090(s.args, s.total_d, s.stream));
     HIP_TRY(c, hipEventRecord(s.ev_scan1, s.stream));
-    HIP_TRY(c, launch_order1090(s.args, s.dense, s.block_sums, s.total_d, s.stream));
+    HIP_TRY(c, launch_order1090(s.args, s.dense, s.decoded, s.block_sums, s.total_d, s.stream));
     HIP_TRY(c, hipMemcpyAsync(s.total_h, s.total_d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(c, hipEventRecord(s.ev_done, s.stream));
     return ADSB_AMD_OK;
@@ -244,6 +254,7 @@ extern "C" void adsb_amd_destroy(adsb_amd_ctx_t* c)
         if (s.work_d) (void)hipFree(s.work_d);
         if (s.total_h) (void)hipHostFree(s.total_h);
         if (s.host) (void)hipHostFree(s.host);
+        if (s.host_dec) (void)hipHostFree(s.host_dec);
         if (s.ev_begin) (void)hipEventDestroy(s.ev_begin);
         if (s.ev_scan0) (void)hipEventDestroy(s.ev_scan0);
         if (s.ev_scan1) (void)hipEventDestroy(s.ev_scan1);
@@ -282,7 +293,7 @@ extern "C" int adsb_amd_scan_1090_submit(adsb_amd_ctx_t* c, const void* iq_devic
 namespace
 {
 // Body of fetch; the caller clears `pending` whatever the outcome, so a failed sync or copy never wedges the slot.
-int fetch_slot(adsb_amd_ctx* c, Slot& s)
+int fetch_slot(adsb_amd_ctx* c, Slot& s, bool with_decoded)
 {
     HIP_TRY(c, hipSetDevice(c->device));
     for (;;)
@@ -297,7 +308,8 @@ int fetch_slot(adsb_amd_ctx* c, Slot& s)
         if (cap > (size_t)2 * kChunk) cap = (size_t)2 * kChunk;
         if (cap == s.cap_per_chunk) return fail(c, ADSB_AMD_EHIP, "record overflow at the maximum region size (internal error)");
         const size_t nch  = s.args.total_chunks ? s.args.total_chunks : 1;
-        const size_t need = 2 * nch * cap * sizeof(adsb_amd_record_t), have = 2 * s.chunks_cap * s.cap_per_chunk * sizeof(adsb_amd_record_t);
+        const size_t per  = 2 * sizeof(adsb_amd_record_t) + sizeof(adsb_amd_decoded_t); // regions + dense + decoded
+        const size_t need = nch * cap * per, have = s.chunks_cap * s.cap_per_chunk * per;
         size_t       free_b = 0, total_b = 0;
         HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
         if (need > free_b + have)
@@ -316,9 +328,12 @@ int fetch_slot(adsb_amd_ctx* c, Slot& s)
     if (s.nrecords)
     {
         HIP_TRY(c, hipMemcpyAsync(s.host, s.dense, s.nrecords * sizeof(adsb_amd_record_t), hipMemcpyDeviceToHost, c->copy_stream));
+        if (with_decoded)
+            HIP_TRY(c, hipMemcpyAsync(s.host_dec, s.decoded, s.nrecords * sizeof(adsb_amd_decoded_t), hipMemcpyDeviceToHost, c->copy_stream));
         HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     }
-    s.timed = true;
+    s.dec_valid = with_decoded;
+    s.timed     = true;
     (void)hipEventElapsedTime(&s.scan_ms, s.ev_scan0, s.ev_scan1);
     (void)hipEventElapsedTime(&s.total_ms, s.ev_begin, s.ev_done);
     return ADSB_AMD_OK;
@@ -333,10 +348,26 @@ extern "C" int adsb_amd_scan_1090_fetch(adsb_amd_ctx_t* c, int slot, const adsb_
     if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
     Slot& s = c->slot[slot];
     if (!s.pending) return fail(c, ADSB_AMD_ESTATE, "fetch without submit");
-    const int rc = fetch_slot(c, s);
+    const int rc = fetch_slot(c, s, false);
     s.pending    = false;
     if (rc) return rc;
     if (records) *records = s.host;
+    if (n) *n = s.nrecords;
+    return ADSB_AMD_OK;
+}
+
+extern "C" int adsb_amd_scan_1090_fetch_decoded(adsb_amd_ctx_t* c, int slot, const adsb_amd_record_t** records, const adsb_amd_decoded_t** decoded,
+                                                size_t* n)
+{
+    if (!c) return ADSB_AMD_EINVAL;
+    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    Slot& s = c->slot[slot];
+    if (!s.pending) return fail(c, ADSB_AMD_ESTATE, "fetch without submit");
+    const int rc = fetch_slot(c, s, true);
+    s.pending    = false;
+    if (rc) return rc;
+    if (records) *records = s.host;
+    if (decoded) *decoded = s.host_dec;
     if (n) *n = s.nrecords;
     return ADSB_AMD_OK;
 }
@@ -499,14 +530,15 @@ extern "C" long adsb_amd_handler_handle_data(adsb_amd_handler_t* h, const uint8_
     int rc = stage_input(c, iq_host, nbytes);
     if (rc) return rc;
     if ((rc = adsb_amd_scan_1090_submit(c, c->staging, nbytes, buffer_bytes, c->stream, 0))) return rc;
-    const adsb_amd_record_t* rec = nullptr;
-    size_t                   n   = 0;
-    if ((rc = adsb_amd_scan_1090_fetch(c, 0, &rec, &n))) return rc;
+    const adsb_amd_record_t*  rec = nullptr;
+    const adsb_amd_decoded_t* dec = nullptr;
+    size_t                    n   = 0;
+    if ((rc = adsb_amd_scan_1090_fetch_decoded(c, 0, &rec, &dec, &n))) return rc;
     const ScanArgs& a = c->slot[0].args;
     // stream position advances by everything the caller handed over, as the reference's HandleData consumes it
     size_t spb  = a.nbuf ? a.buf_samples : nbytes / 2;
     size_t nbuf = a.nbuf ? a.nbuf : 1;
-    return h->resolver.feed(rec, n, spb, nbuf, cb, user);
+    return h->resolver.feed(rec, dec, n, spb, nbuf, cb, user);
 }
 
 // Recorded-file replay: what RTLSDR::TestDataReadLoop (RTLSDR.hpp:419-442) does for a handler -- whole BufferLength
@@ -595,7 +627,45 @@ extern "C" long adsb_amd_resolver_feed(adsb_amd_resolver_t* r, const adsb_amd_re
                                        size_t nbuffers, adsb_amd_on_changed_fn cb, void* user)
 {
     if (!r) return ADSB_AMD_EINVAL;
-    return r->impl.feed(records, n, samples_per_buffer, nbuffers, cb, user);
+    return r->impl.feed(records, nullptr, n, samples_per_buffer, nbuffers, cb, user);
+}
+extern "C" long adsb_amd_resolver_feed_decoded(adsb_amd_resolver_t* r, const adsb_amd_record_t* records, const adsb_amd_decoded_t* decoded, size_t n,
+                                               size_t samples_per_buffer, size_t nbuffers, adsb_amd_on_changed_fn cb, void* user)
+{
+    if (!r || (n && !decoded)) return ADSB_AMD_EINVAL;
+    return r->impl.feed(records, decoded, n, samples_per_buffer, nbuffers, cb, user);
+}
+extern "C" int adsb_amd_cpr_nl(double lat) { return adsb_amd::cpr_nl(lat); }
+extern "C" int adsb_amd_cpr_global(double even_lat, double even_lon, double odd_lat, double odd_lon, int use_even, int32_t* lat1e7, int32_t* lon1e7)
+{
+    return adsb_amd::cpr_global(even_lat, even_lon, odd_lat, odd_lon, use_even != 0, lat1e7, lon1e7) ? 1 : 0;
+}
+extern "C" void adsb_amd_decode_record_host(const adsb_amd_record_t* record, adsb_amd_decoded_t* out)
+{
+    if (record && out) *out = adsb_amd::decode_record(record->msg, record->df);
+}
+extern "C" int adsb_amd_decode_1090(adsb_amd_ctx_t* c, const adsb_amd_record_t* records_host, size_t n, adsb_amd_decoded_t* out_host)
+{
+    if (!c) return ADSB_AMD_EINVAL;
+    if (n == 0) return ADSB_AMD_OK;
+    if (!records_host || !out_host) return fail(c, ADSB_AMD_EINVAL, "NULL array");
+    HIP_TRY(c, hipSetDevice(c->device));
+    adsb_amd_record_t*  d_rec = nullptr;
+    adsb_amd_decoded_t* d_out = nullptr;
+    hipError_t          e     = hipMalloc(&d_rec, n * sizeof(adsb_amd_record_t));
+    if (e == hipSuccess) e = hipMalloc(&d_out, n * sizeof(adsb_amd_decoded_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rec, records_host, n * sizeof(adsb_amd_record_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_decode1090(d_rec, d_out, n, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, d_out, n * sizeof(adsb_amd_decoded_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (d_rec) (void)hipFree(d_rec);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess)
+    {
+        c->error = std::string("decode_1090: ") + hipGetErrorString(e);
+        return ADSB_AMD_EHIP;
+    }
+    return ADSB_AMD_OK;
 }
 /* A listener that only counts: *(uint64_t*)user += 1 per accepted frame.  For rate measurements through the callback path
  * without a foreign-language trampoline in the loop. */

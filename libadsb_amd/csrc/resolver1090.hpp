@@ -4,8 +4,9 @@
 // inherently sequential (reference ADSB1090.cpp:886-957): a frame accepted at j hides the next 128/240 offsets,
 // AP-type DFs are valid only if their address was recently seen in a clean DF11/17 (:195-207, :396-435), and the
 // retry slice is only looked at when the first slice was not accepted.  Resolver1090 walks the sorted records once
-// and applies exactly those rules, then decodes the fields the aircraft update consumes (:530-672), runs the
-// global CPR decode (:1079-1121) and fires the callback for every accepted frame (:1124-1175).
+// and applies exactly those rules, takes the fields the aircraft update consumes (:530-672) -- decoded by the GPU in
+// its ordering pass, or here by the same function (decode1090.h) --, runs the global CPR decode (:1079-1121) and fires
+// the callback for every accepted frame (:1124-1175).
 #pragma once
 
 #include <array>
@@ -18,22 +19,7 @@
 namespace adsb_amd
 {
 
-// Fields of one decoded Mode S message that the aircraft update uses (the reference's `Message`, ADSB1090.cpp:32-97).
-struct ModesFields
-{
-    int      df = 0, nbits = 0, errorbit = -1;
-    uint32_t icao   = 0;
-    int      metype = 0, mesub = 0;
-    bool     odd      = false; // CPR format flag
-    int      raw_lat  = 0, raw_lon = 0;
-    int      altitude = 0;
-    int      velocity = 0, heading = 0;
-    int      identity = 0; // squawk as four decimal digits
-    std::array<char, 8> flight{};
-};
-
-ModesFields decode_fields(const uint8_t msg[14], int df, int nbits, int errorbit, uint32_t icao);
-int         cpr_nl(double lat);
+int cpr_nl(double lat);
 // Global airborne CPR from an even and an odd frame; false when the two latitudes fall in different NL zones.
 bool cpr_global(double even_lat, double even_lon, double odd_lat, double odd_lon, bool use_even, int32_t* lat1e7, int32_t* lon1e7);
 
@@ -42,86 +28,96 @@ class Resolver1090
   public:
     // rate_hz == 0: wall clock like the reference; otherwise the stream time of the sample.
     void   set_sample_clock(int64_t t0_ns, uint32_t rate_hz);
-    long   feed(const adsb_amd_record_t* rec, size_t n, size_t samples_per_buffer, size_t nbuffers, adsb_amd_on_changed_fn cb, void* user);
+    // `dec` (parallel to `rec`): the GPU's decoded fields (adsb_amd_scan_1090_fetch_decoded); NULL: decode on the host (decode1090.h).
+    long   feed(const adsb_amd_record_t* rec, const adsb_amd_decoded_t* dec, size_t n, size_t samples_per_buffer, size_t nbuffers,
+                adsb_amd_on_changed_fn cb, void* user);
     size_t aircraft_count() const { return table_.size(); }
 
   private:
     struct Track
     {
+        int64_t             seen_ns = 0; // last clean DF11/17 (the reference's ICAO cache entry, :195-207); valid when `seen`
+        bool                seen    = false;
         adsb_amd_aircraft_t pub{};
         double              even_lat = 0, even_lon = 0, odd_lat = 0, odd_lon = 0;
         int64_t             even_ns = 0, odd_ns = 0; // 0 = never (the reference's default time_point)
-        int64_t             seen_ns = 0;             // last clean DF11/17 (the reference's ICAO cache entry, :195-207)
-        bool                seen    = false;
     };
     // The reference keeps two unordered_maps keyed by the 24-bit address (ICAO cache :195-207, TrafficManager's aircraft,
     // AircraftImpl.h:49-68).  Every address enters both at the same moment (a clean DF11/17 is accepted in the same step
     // that whitelists it), so one open-addressing table serves both: one probe per frame instead of two hash look-ups.
+    // The probe array holds only {address + 1, index} (8 bytes a slot, a few KiB for a busy sky, resident in L1); the
+    // aircraft records live in a separate array that only the update touches.
     class AddrTable
     {
       public:
-        AddrTable() : slots_(1024) {}
+        AddrTable() : slots_(1024) { tracks_.reserve(512); }
         Track* find(uint32_t addr)
         {
+            const uint32_t key = addr + 1u;
             for (size_t i = hash(addr) & (slots_.size() - 1);; i = (i + 1) & (slots_.size() - 1))
             {
-                if (!slots_[i].used) return nullptr;
-                if (slots_[i].addr == addr) return &slots_[i].track;
+                if (slots_[i].key == 0) return nullptr;
+                if (slots_[i].key == key) return &tracks_[slots_[i].index];
             }
         }
         Track& get_or_create(uint32_t addr, bool* created)
         {
-            if ((count_ + 1) * 2 > slots_.size()) grow();
+            const uint32_t key = addr + 1u;
             for (size_t i = hash(addr) & (slots_.size() - 1);; i = (i + 1) & (slots_.size() - 1))
             {
-                if (!slots_[i].used)
-                {
-                    slots_[i].used = true;
-                    slots_[i].addr = addr;
-                    count_++;
-                    *created = true;
-                    return slots_[i].track;
-                }
-                if (slots_[i].addr == addr)
+                if (slots_[i].key == key)
                 {
                     *created = false;
-                    return slots_[i].track;
+                    return tracks_[slots_[i].index];
+                }
+                if (slots_[i].key == 0)
+                {
+                    if ((tracks_.size() + 1) * 2 > slots_.size())
+                    {
+                        grow();
+                        return get_or_create(addr, created);
+                    }
+                    slots_[i].key   = key;
+                    slots_[i].index = (uint32_t)tracks_.size();
+                    tracks_.emplace_back();
+                    *created = true;
+                    return tracks_.back();
                 }
             }
         }
-        size_t size() const { return count_; }
+        size_t size() const { return tracks_.size(); }
 
       private:
         struct Slot
         {
-            uint32_t addr = 0;
-            bool     used = false;
-            Track    track;
+            uint32_t key = 0; // address + 1; 0 = empty (addresses are 24 bits, the AP xor parity candidates at most 24 as well)
+            uint32_t index = 0;
         };
         static size_t hash(uint32_t a) { return (size_t)((a * 0x9E3779B1u) >> 8); }
         void          grow()
         {
             std::vector<Slot> old;
             old.swap(slots_);
-            slots_.resize(old.size() * 2);
-            count_ = 0;
-            for (Slot& s : old)
-                if (s.used)
+            slots_.assign(old.size() * 2, Slot{});
+            for (const Slot& s : old)
+                if (s.key)
                 {
-                    bool c;
-                    get_or_create(s.addr, &c) = s.track;
+                    size_t i = hash(s.key - 1u) & (slots_.size() - 1);
+                    while (slots_[i].key) i = (i + 1) & (slots_.size() - 1);
+                    slots_[i] = s;
                 }
         }
-        std::vector<Slot> slots_;
-        size_t            count_ = 0;
+        std::vector<Slot>  slots_;
+        std::vector<Track> tracks_; // references handed out stay valid until the next get_or_create
     };
-    int64_t now_ns(uint64_t stream_sample) const;
-    void    apply(const ModesFields& f, int64_t t, Track& a);
+    void apply(const adsb_amd_decoded_t& d, int64_t t, Track& a);
 
-    AddrTable                             table_;
-    int64_t                               t0_ns_       = 0;
-    uint32_t                              rate_hz_     = 0;
-    uint64_t                              stream_base_ = 0;
+    AddrTable table_;
+    int64_t   t0_ns_       = 0;
+    uint32_t  rate_hz_     = 0;
+    uint64_t  ns_per_sample_ = 0; // 10^9 / rate when that is a whole number (2 MS/s: 500), else 0
+    uint64_t  rate_recip_  = 0;   // floor(2^64 / rate): quotient estimate for the exact division by the rate
+    uint64_t  stream_base_ = 0;
 };
 
 } // namespace adsb_amd

@@ -65,7 +65,10 @@ hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipS
 // Ordering pass: per-block record sums, then the sorted gather into `dense`.  `total_and_overflow` is a device
 // uint32_t[2]: {number of records in dense, overflow flag}; `block_sums` holds one uint32_t per 256 chunks.  It only
 // touches records, so it may run on another stream beside the next scan.
-hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t* block_sums, uint32_t* total_and_overflow, hipStream_t stream);
+hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, adsb_amd_decoded_t* decoded, uint32_t* block_sums, uint32_t* total_and_overflow,
+                            hipStream_t stream);
+// the field decoder of the ordering pass over an arbitrary device record array (parity helper)
+hipError_t launch_decode1090(const adsb_amd_record_t* rec, adsb_amd_decoded_t* out, size_t n, hipStream_t stream);
 
 // magnitudes exactly as the reference computes them (parity helper)
 hipError_t launch_magnitude1090(const uint8_t* iq, uint16_t* mag, size_t nsamples, hipStream_t stream);

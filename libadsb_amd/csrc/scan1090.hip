@@ -33,6 +33,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "decode1090.h"
 #include "scan1090.h"
 
 namespace adsb_amd
@@ -956,7 +957,8 @@ __device__ __forceinline__ uint32_t msg_bytes(uint32_t bits) { return __builtin_
 __global__ __launch_bounds__(256) void gather_sorted_kernel(const adsb_amd_record_t* __restrict__ chunk_records,
                                                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ block_sums,
                                                             uint32_t nchunks, uint32_t nblocks, uint32_t cap, uint32_t chunks_per_buf,
-                                                            adsb_amd_record_t* __restrict__ dense, uint32_t* __restrict__ total_overflow)
+                                                            adsb_amd_record_t* __restrict__ dense, adsb_amd_decoded_t* __restrict__ decoded,
+                                                            uint32_t* __restrict__ total_overflow)
 {
     __shared__ uint32_t wave_tot[4];
     // records in earlier blocks
@@ -1012,7 +1014,26 @@ __global__ __launch_bounds__(256) void gather_sorted_kernel(const adsb_amd_recor
         uint4* o = reinterpret_cast<uint4*>(dst + rank);
         o[0]     = o0;
         o[1]     = o1;
+        // the stateless half of DecodeModesMessage (decode1090.h), so that the host's sequential pass decodes nothing
+        uint8_t g[16];
+        g[0] = (uint8_t)m0; g[1] = (uint8_t)(m0 >> 8); g[2] = (uint8_t)(m0 >> 16); g[3] = (uint8_t)(m0 >> 24);
+        g[4] = (uint8_t)m1; g[5] = (uint8_t)(m1 >> 8); g[6] = (uint8_t)(m1 >> 16); g[7] = (uint8_t)(m1 >> 24);
+        g[8] = (uint8_t)m2; g[9] = (uint8_t)(m2 >> 8); g[10] = (uint8_t)(m2 >> 16); g[11] = (uint8_t)(m2 >> 24);
+        g[12] = (uint8_t)m3; g[13] = (uint8_t)(m3 >> 8);
+        const adsb_amd_decoded_t d = decode_record(g, (int)df);
+        *reinterpret_cast<uint4*>(decoded + (base + incl - n) + rank) =
+            make_uint4((uint32_t)d.kind | ((uint32_t)d.metype << 8) | ((uint32_t)d.mesub << 16) | ((uint32_t)d.odd << 24), (uint32_t)d.altitude, d.a, d.b);
     }
+}
+
+// parity helper: the same decoder over an arbitrary record array
+__global__ __launch_bounds__(256) void decode1090_kernel(const adsb_amd_record_t* __restrict__ rec, adsb_amd_decoded_t* __restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t g[14];
+    for (int k = 0; k < 14; k++) g[k] = rec[i].msg[k];
+    out[i] = decode_record(g, rec[i].df);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1058,14 +1079,22 @@ hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipS
     return hipGetLastError();
 }
 
-hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, uint32_t* block_sums, uint32_t* total_and_overflow, hipStream_t stream)
+hipError_t launch_decode1090(const adsb_amd_record_t* rec, adsb_amd_decoded_t* out, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(decode1090_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, rec, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, adsb_amd_decoded_t* decoded, uint32_t* block_sums, uint32_t* total_and_overflow,
+                            hipStream_t stream)
 {
     if (a.total_chunks == 0) return hipSuccess;
     const uint32_t nblocks = (a.total_chunks + kOrderBlock - 1u) / kOrderBlock;
     hipLaunchKernelGGL(block_sums_kernel, dim3(nblocks), dim3(kOrderBlock), 0, stream, a.chunk_counts, block_sums, a.total_chunks, a.cap,
                        total_and_overflow, a.work_counters);
     hipLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderBlock), 0, stream, a.chunk_records, a.chunk_counts, block_sums, a.total_chunks,
-                       nblocks, a.cap, a.chunks_per_buf, dense, total_and_overflow);
+                       nblocks, a.cap, a.chunks_per_buf, dense, decoded, total_and_overflow);
     return hipGetLastError();
 }
 

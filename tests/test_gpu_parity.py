@@ -404,3 +404,56 @@ def test_root_gather_over_rccl_world_of_one(native_libs, tmp_path):
                 str(script)])
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
     assert "NCCL-OK" in out.stdout
+
+
+def test_device_field_decoder_equals_the_host_build(scanner):
+    """The ordering pass decodes every record's fields on the GPU (decode1090.h).  Device == host build on: the records of a real
+    scan (as delivered beside the records), every (east-west, north-south) velocity pair -- 4.2 million headings, the one place
+    where two math libraries meet --, and records with random bytes."""
+    import torch
+    iq, _ = synth.fill_range(500, 16)
+    d = torch.from_numpy(iq).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    scanner.submit(d.data_ptr(), d.numel(), BB, st, 0)
+    rec, dec = scanner.fetch_decoded(0)
+    H.assert_records_equal(rec, scanner.scan(iq, BB))
+    assert len(rec) > 1000 and np.array_equal(dec, A.decode_records_host(rec))
+    assert set(np.unique(dec["kind"])) == {0, 1, 2, 3, 4}
+    # every velocity pair, checked against the reference's expression evaluated with numpy's (= the host's libm) atan2
+    e, n = np.meshgrid(np.arange(-1023, 1024), np.arange(-1023, 1024), indexing="ij")
+    e, n = e.ravel(), n.ravel()
+    vel = np.zeros(e.size, dtype=A.RECORD_DTYPE)
+    vel["df"], vel["nbits"] = 17, 112
+    m = vel["msg"]
+    m[:, 0], m[:, 4] = 17 << 3, (19 << 3) | 1
+    m[:, 5] = np.where(e < 0, 4, 0) | ((np.abs(e) >> 8) & 3)
+    m[:, 6] = np.abs(e) & 0xFF
+    m[:, 7] = np.where(n < 0, 0x80, 0) | ((np.abs(n) >> 3) & 0x7F)
+    m[:, 8] = (np.abs(n) & 7) << 5
+    got = scanner.decode(vel)
+    speed = np.floor(np.sqrt((n * n + e * e).astype(np.float64))).astype(np.int64)
+    hd = np.trunc(np.arctan2(e.astype(np.float64), n.astype(np.float64)) * 360 / (np.pi * 2)).astype(np.int64)
+    hd = np.where(hd < 0, hd + 360, hd)
+    hd = np.where(speed == 0, 0, hd)
+    assert np.all(got["kind"] == A.K_VELOCITY) and np.array_equal(got["a"], speed) and np.array_equal(got["b"].astype(np.int64), hd)
+    # a sample of those through the host build as well (it is a Python loop)
+    pick = np.random.default_rng(5).choice(e.size, 3000, replace=False)
+    assert np.array_equal(got[pick], A.decode_records_host(vel[pick]))
+    rnd = np.zeros(20000, dtype=A.RECORD_DTYPE)
+    rng = np.random.default_rng(9)
+    rnd["msg"] = rng.integers(0, 256, size=(20000, 14), dtype=np.uint8)
+    rnd["df"] = rng.choice([0, 4, 5, 11, 16, 17, 20, 21, 24, 17, 17], 20000)
+    assert np.array_equal(scanner.decode(rnd), A.decode_records_host(rnd))
+
+
+def test_resolver_on_gpu_decoded_fields_equals_oracle(scanner):
+    # records + GPU-decoded fields through the host resolver == the oracle's sequential loop (frames, aircraft, callback text)
+    import torch
+    iq, _ = synth.fill_range(77, 24)
+    d = torch.from_numpy(iq).cuda()
+    scanner.submit(d.data_ptr(), d.numel(), BB, torch.cuda.current_stream().cuda_stream, 0)
+    rec, dec = scanner.fetch_decoded(0)
+    n, fr, ac = A.Resolver().feed(rec, BB // 2, 24, decoded=dec)
+    ofr, oac = H.oracle_run(iq, BB)
+    H.assert_streams_equal(fr, ac, ofr, oac)
+    assert H.callback_text(ac) == H.callback_text(oac) and n == len(ofr) > 1000
