@@ -214,6 +214,25 @@ void adsb_amd_host_free(void* p);
 long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* path, size_t first_buffer, size_t max_buffers, adsb_amd_on_changed_fn cb,
                                   void* user);
 
+/* ---------------------------------------------------------------- sample transport (stand-alone stand-in for RTLSDR's ring)
+ * What the reference's RTLSDR class does for a handler, without librtlsdr (RTLSDR.hpp:55-56, 396-442, 493-539, 564-570): a ring of
+ * 16 slots of 262144 bytes (page-locked when a GPU runtime is present) between one producer and one consumer thread.  The producer
+ * is the replay of a recorded file (replay_path: whole 262144-byte reads in file order, re-opened at its end when loop != 0, a
+ * trailing partial read never delivered) or the caller of adsb_amd_transport_push (RTLSDR::OnDataAvailable: the USB callback of
+ * a host that owns the receiver; blocks while the ring is full).  The consumer thread hands one slot at a time to `sink`. */
+typedef struct adsb_amd_transport adsb_amd_transport_t;
+typedef void (*adsb_amd_buffer_fn)(void* user, const uint8_t* data, size_t nbytes);
+int  adsb_amd_transport_create(adsb_amd_transport_t** out, const char* replay_path /* NULL: push mode */, int loop);
+void adsb_amd_transport_destroy(adsb_amd_transport_t* t);
+int  adsb_amd_transport_start(adsb_amd_transport_t* t, adsb_amd_buffer_fn sink, void* user); /* EINVAL when the file cannot be opened */
+int  adsb_amd_transport_stop(adsb_amd_transport_t* t);                                       /* joins both threads */
+int  adsb_amd_transport_push(adsb_amd_transport_t* t, const uint8_t* data, size_t nbytes);    /* EINVAL unless nbytes % 262144 == 0 */
+int  adsb_amd_transport_stats(const adsb_amd_transport_t* t, uint64_t* delivered, int* producer_done, int* page_locked);
+/* The reference's replay mode end to end in native code: the file through the ring, one HandleData per slot on the consumer
+ * thread (callbacks fire there, in order), until the file has been delivered once.  Returns the accepted frames or an error;
+ * *buffers / *seconds (optional) receive the slots delivered and the wall time. */
+long adsb_amd_handler_run_replay(adsb_amd_handler_t* h, const char* path, adsb_amd_on_changed_fn cb, void* user, uint64_t* buffers, double* seconds);
+
 /* =====================================================================================================================
  * UAT 978.  Boundary replaced:
  *   UAT978Handler::HandleData(std::span<uint8_t const>)                     UAT978.cpp:43-60   -> adsb_amd_uat_handle_data

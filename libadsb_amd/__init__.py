@@ -33,7 +33,9 @@ EXPORTS = [
     "adsb_amd_decode_1090", "adsb_amd_decode_record_host", "adsb_amd_resolver_feed_decoded", "adsb_amd_cpr_nl", "adsb_amd_cpr_global",
     "adsb_amd_resolver_create", "adsb_amd_resolver_destroy", "adsb_amd_resolver_set_sample_clock", "adsb_amd_resolver_feed",
     "adsb_amd_resolver_aircraft_count", "adsb_amd_count_callback", "adsb_amd_handler_create", "adsb_amd_handler_destroy", "adsb_amd_handler_last_error",
-    "adsb_amd_handler_set_sample_clock", "adsb_amd_handler_handle_data", "adsb_amd_handler_replay_file", "adsb_amd_host_alloc", "adsb_amd_host_free",
+    "adsb_amd_handler_set_sample_clock", "adsb_amd_handler_handle_data", "adsb_amd_handler_replay_file", "adsb_amd_handler_run_replay", "adsb_amd_host_alloc", "adsb_amd_host_free",
+    "adsb_amd_transport_create", "adsb_amd_transport_destroy", "adsb_amd_transport_start", "adsb_amd_transport_stop", "adsb_amd_transport_push",
+    "adsb_amd_transport_stats",
     "adsb_amd_uat_create", "adsb_amd_uat_destroy", "adsb_amd_uat_last_error", "adsb_amd_uat_handle_data", "adsb_amd_uat_set_carry_full",
     "adsb_amd_uat_stream_state", "adsb_amd_uat_process_phases", "adsb_amd_uat_process_iq", "adsb_amd_uat_timing", "adsb_amd_uat_host_timing", "adsb_amd_uat_phase_lut",
     "adsb_amd_uat_rs_decode", "adsb_amd_uat_rs_decode_device", "adsb_amd_uat_set_dump_raw_message", "init_fec", "process_buffer",
@@ -95,6 +97,14 @@ def lib():
         L.adsb_amd_handler_handle_data.restype = C.c_long
         L.adsb_amd_handler_replay_file.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
         L.adsb_amd_handler_replay_file.restype = C.c_long
+        L.adsb_amd_handler_run_replay.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        L.adsb_amd_handler_run_replay.restype = C.c_long
+        L.adsb_amd_transport_create.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_int]
+        L.adsb_amd_transport_destroy.argtypes = [C.c_void_p]
+        L.adsb_amd_transport_start.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.adsb_amd_transport_stop.argtypes = [C.c_void_p]
+        L.adsb_amd_transport_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.adsb_amd_transport_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.adsb_amd_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         L.adsb_amd_host_free.argtypes = [C.c_void_p]
         L.adsb_amd_uat_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
@@ -306,12 +316,77 @@ class Handler1090:
         """RTLSDR::TestDataReadLoop for one pass over a recorded u8 IQ file (whole 262144-B buffers).  Returns
         (accepted frame count, frames, aircraft)."""
         col = _Collector()
-        cb = C.cast(col.cb, C.c_void_p) if collect else None
-        n = self._l.adsb_amd_handler_replay_file(self._h, os.fsencode(path), first_buffer, max_buffers, cb, None)
+        counter = C.c_uint64(0)
+        if collect:
+            cb, user = C.cast(col.cb, C.c_void_p), None
+        else:  # the library's counting listener: the callback path at native speed
+            cb, user = C.cast(self._l.adsb_amd_count_callback, C.c_void_p), C.cast(C.pointer(counter), C.c_void_p)
+        n = self._l.adsb_amd_handler_replay_file(self._h, os.fsencode(path), first_buffer, max_buffers, cb, user)
         if n < 0:
             raise AdsbAmdError("replay_file failed (%d): %s" % (n, self._l.adsb_amd_handler_last_error(self._h).decode()))
         fr, ac = col.arrays()
         return n, fr, ac
+
+
+    def run_replay(self, path, collect=True):
+        """libadsb's replay mode in native code: the file through the 16-slot ring, one HandleData per 262144-byte slot on the
+        transport's consumer thread.  Returns (accepted frames, frames, aircraft, slots delivered, seconds)."""
+        col = _Collector()
+        counter = C.c_uint64(0)
+        if collect:
+            cb, user = C.cast(col.cb, C.c_void_p), None
+        else:
+            cb, user = C.cast(self._l.adsb_amd_count_callback, C.c_void_p), C.cast(C.pointer(counter), C.c_void_p)
+        nb, sec = C.c_uint64(), C.c_double()
+        n = self._l.adsb_amd_handler_run_replay(self._h, os.fsencode(path), cb, user, C.byref(nb), C.byref(sec))
+        if n < 0:
+            raise AdsbAmdError("run_replay failed (%d): %s" % (n, self._l.adsb_amd_handler_last_error(self._h).decode()))
+        fr, ac = col.arrays()
+        return n, fr, ac, nb.value, sec.value
+
+
+BUFFER_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+
+
+class Transport:
+    """The stand-alone sample transport (transport.hpp): 16 x 262144-byte ring, producer = file replay or push(), consumer thread
+    -> sink(bytes).  Needs no GPU (the slots are page-locked only when a HIP runtime is usable)."""
+
+    def __init__(self, replay_path=None, loop=False):
+        self._l = lib()
+        self._h = C.c_void_p()
+        rc = self._l.adsb_amd_transport_create(C.byref(self._h), os.fsencode(replay_path) if replay_path else None, 1 if loop else 0)
+        if rc != 0:
+            raise AdsbAmdError("adsb_amd_transport_create failed (%d)" % rc)
+        self._cb = None
+
+    def start(self, sink):
+        self._cb = BUFFER_FN(lambda _u, p, n: sink(C.string_at(p, n)))
+        rc = self._l.adsb_amd_transport_start(self._h, C.cast(self._cb, C.c_void_p), None)
+        if rc != 0:
+            raise AdsbAmdError("adsb_amd_transport_start failed (%d): cannot open the recording" % rc)
+
+    def push(self, data):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        rc = self._l.adsb_amd_transport_push(self._h, data.ctypes.data, data.size)
+        if rc != 0:
+            raise AdsbAmdError("adsb_amd_transport_push failed (%d): size must be a multiple of 262144" % rc)
+
+    def stats(self):
+        d, done, pl = C.c_uint64(), C.c_int(), C.c_int()
+        self._l.adsb_amd_transport_stats(self._h, C.byref(d), C.byref(done), C.byref(pl))
+        return {"delivered": d.value, "producer_done": bool(done.value), "page_locked": bool(pl.value)}
+
+    def stop(self):
+        self._l.adsb_amd_transport_stop(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.adsb_amd_transport_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 class PinnedBuffer:

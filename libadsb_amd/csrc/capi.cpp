@@ -9,6 +9,11 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cerrno>
 
 #include <cstdio>
@@ -22,6 +27,7 @@
 #include "decode1090.h"
 #include "resolver1090.hpp"
 #include "scan1090.h"
+#include "transport.hpp"
 
 using namespace adsb_amd;
 
@@ -541,10 +547,12 @@ extern "C" long adsb_amd_handler_handle_data(adsb_amd_handler_t* h, const uint8_
     return h->resolver.feed(rec, dec, n, spb, nbuf, cb, user);
 }
 
-// Recorded-file replay: what RTLSDR::TestDataReadLoop (RTLSDR.hpp:419-442) does for a handler -- whole BufferLength
+// Recorded-file replay in batches: what RTLSDR::TestDataReadLoop (RTLSDR.hpp:419-442) feeds a handler -- whole BufferLength
 // (262 144 B) reads in file order, each buffer demodulated on its own, a trailing partial read never delivered -- for one
 // pass over buffers [first_buffer, first_buffer + max_buffers) of the file (the reference re-opens the file and loops until
-// stopped; ranks of a multi-GPU job take disjoint ranges).  The file is mapped and handed to the batch path in slices.
+// stopped; ranks of a multi-GPU job take disjoint ranges).  The file is mapped; batches of 256 buffers go through a two-stage
+// pipeline (upload of batch k+1 beside scan of k and resolve of k-1).  adsb_amd_handler_run_replay below is the same file through
+// the ring, one buffer per HandleData, the way libadsb's replay mode paces it.
 extern "C" long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* path, size_t first_buffer, size_t max_buffers,
                                              adsb_amd_on_changed_fn cb, void* user)
 {
@@ -571,30 +579,119 @@ extern "C" long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* 
         return 0;
     }
     const size_t nbuf = std::min(max_buffers, total - first_buffer);
-    void*        map  = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (map == MAP_FAILED)
+    const size_t   kSlice = 256; // buffers per batch (64 MiB)
+    const size_t   nbatch = (nbuf + kSlice - 1) / kSlice;
+    adsb_amd_ctx*  c      = h->ctx;
+    // Two device staging buffers, two page-locked host buffers and an uploader thread: while the GPU scans batch k and this thread
+    // resolves batch k-1, the uploader reads batch k+1 (pread by eight threads straight into page-locked memory: from the page
+    // cache that is a copy at memory speed, and the upload that follows is a DMA; handing the runtime a mapping of the file
+    // instead was measured at 7.7 GB/s) and sends it to the device.  Buffers stay independent (a batch is a whole number of them),
+    // the resolver sees the batches in file order, so the callback stream is the one of buffer-by-buffer delivery.
+    uint8_t* stage[2] = {nullptr, nullptr};
+    uint8_t* pinned[2] = {nullptr, nullptr};
+    long     accepted = 0;
+    auto     cleanup  = [&]() {
+        for (uint8_t* p : stage)
+            if (p) (void)hipFree(p);
+        for (uint8_t* p : pinned)
+            if (p) (void)hipHostFree(p);
+        close(fd);
+    };
+    if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&stage[0], kSlice * BB) != hipSuccess || hipMalloc(&stage[1], kSlice * BB) != hipSuccess ||
+        hipHostMalloc(&pinned[0], kSlice * BB, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&pinned[1], kSlice * BB, hipHostMallocDefault) != hipSuccess)
     {
-        h->error = std::string("mmap ") + path + ": " + strerror(errno);
-        return ADSB_AMD_EINVAL;
+        h->error = "replay_file: cannot allocate the staging buffers";
+        cleanup();
+        return ADSB_AMD_EHIP;
     }
-    (void)madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
-    const uint8_t* base     = static_cast<const uint8_t*>(map) + first_buffer * BB;
-    const size_t   kSlice   = 1024; // buffers per batch (256 MiB)
-    long           accepted = 0;
-    for (size_t b = 0; b < nbuf; b += kSlice)
-    {
-        const size_t n  = std::min(kSlice, nbuf - b);
-        const long   rc = adsb_amd_handler_handle_data(h, base + b * BB, n * BB, BB, cb, user);
-        if (rc < 0)
+    std::mutex              mu;
+    std::condition_variable cv;
+    size_t                  uploaded = 0, released = 0; // batches whose upload is complete / whose staging buffer is free again
+    std::atomic<bool>       failed{false};
+    std::thread             uploader([&]() {
+        if (hipSetDevice(c->device) != hipSuccess) failed = true;
+        for (size_t b = 0; b < nbatch && !failed; b++)
         {
-            accepted = rc;
-            break;
+            {
+                std::unique_lock lk(mu);
+                cv.wait(lk, [&]() { return b < released + 2 || failed; });
+                if (failed) break;
+            }
+            const size_t n     = std::min(kSlice, nbuf - b * kSlice);
+            const size_t bytes = n * BB;
+            const off_t  at    = (off_t)((first_buffer + b * kSlice) * BB);
+            {
+                constexpr int    kReaders = 8;
+                std::atomic<int> bad{0};
+                std::thread      rd[kReaders];
+                for (int t = 0; t < kReaders; t++)
+                    rd[t] = std::thread([&, t]() {
+                        size_t lo = bytes * (size_t)t / kReaders, hi = bytes * (size_t)(t + 1) / kReaders;
+                        while (lo < hi)
+                        {
+                            const ssize_t r = pread(fd, pinned[b & 1] + lo, hi - lo, at + (off_t)lo);
+                            if (r <= 0)
+                            {
+                                bad = 1;
+                                return;
+                            }
+                            lo += (size_t)r;
+                        }
+                    });
+                for (auto& t : rd) t.join();
+                if (bad) failed = true;
+            }
+            if (!failed && hipMemcpy(stage[b & 1], pinned[b & 1], bytes, hipMemcpyHostToDevice) != hipSuccess) failed = true;
+            std::unique_lock lk(mu);
+            uploaded = b + 1;
+            cv.notify_all();
         }
-        accepted += rc;
+        std::unique_lock lk(mu);
+        cv.notify_all();
+    });
+    auto resolve = [&](size_t b) -> int { // batch b was submitted on slot b & 1
+        const adsb_amd_record_t*  rec = nullptr;
+        const adsb_amd_decoded_t* dec = nullptr;
+        size_t                    nr  = 0;
+        int                       rc  = adsb_amd_scan_1090_fetch_decoded(c, (int)(b & 1), &rec, &dec, &nr);
+        if (rc) return rc;
+        const size_t n = std::min(kSlice, nbuf - b * kSlice);
+        const long   a = h->resolver.feed(rec, dec, nr, BB / 2, n, cb, user);
+        if (a < 0) return (int)a;
+        accepted += a;
+        std::unique_lock lk(mu);
+        released = b + 1;
+        cv.notify_all();
+        return 0;
+    };
+    int rc = 0;
+    for (size_t b = 0; b < nbatch && !rc; b++)
+    {
+        {
+            std::unique_lock lk(mu);
+            cv.wait(lk, [&]() { return uploaded > b || failed; });
+            if (failed) break;
+        }
+        const size_t n = std::min(kSlice, nbuf - b * kSlice);
+        rc             = adsb_amd_scan_1090_submit(c, stage[b & 1], n * BB, BB, c->stream, (int)(b & 1));
+        if (!rc && b > 0) rc = resolve(b - 1);
     }
-    munmap(map, (size_t)st.st_size);
-    return accepted;
+    if (!rc && !failed && nbatch > 0) rc = resolve(nbatch - 1);
+    {
+        std::unique_lock lk(mu);
+        if (rc) failed = true;
+        cv.notify_all();
+    }
+    uploader.join();
+    (void)hipDeviceSynchronize();
+    for (Slot& sl : c->slot) sl.pending = false; // a failed run may leave a submitted scan behind
+    if (failed && !rc)
+    {
+        h->error = "replay_file: upload failed";
+        rc       = ADSB_AMD_EHIP;
+    }
+    cleanup();
+    return rc ? rc : accepted;
 }
 
 // Transport helper: a host that keeps its IQ ring (RTLSDR.hpp:564-570 keeps BufferCount slots of BufferLength bytes) in
@@ -674,3 +771,113 @@ extern "C" void adsb_amd_count_callback(void* user, const adsb_amd_frame_t* /*fr
     if (user) ++*static_cast<uint64_t*>(user);
 }
 extern "C" size_t adsb_amd_resolver_aircraft_count(const adsb_amd_resolver_t* r) { return r ? r->impl.aircraft_count() : 0; }
+
+// ------------------------------------------------------------------------------------------------ transport
+struct adsb_amd_transport final : adsb_amd::Transport::Sink
+{
+    adsb_amd_transport(const char* path, bool loop) : impl(path ? path : "", loop) {}
+    void Deliver(const uint8_t* data, size_t nbytes) override
+    {
+        if (sink) sink(user, data, nbytes);
+    }
+    adsb_amd::Transport impl;
+    adsb_amd_buffer_fn  sink = nullptr;
+    void*               user = nullptr;
+};
+
+extern "C" int adsb_amd_transport_create(adsb_amd_transport_t** out, const char* replay_path, int loop)
+{
+    if (!out) return ADSB_AMD_EINVAL;
+    *out = nullptr;
+    try
+    {
+        *out = new adsb_amd_transport(replay_path, loop != 0);
+    } catch (...)
+    {
+        return ADSB_AMD_EHIP;
+    }
+    return ADSB_AMD_OK;
+}
+extern "C" void adsb_amd_transport_destroy(adsb_amd_transport_t* t) { delete t; }
+extern "C" int  adsb_amd_transport_start(adsb_amd_transport_t* t, adsb_amd_buffer_fn sink, void* user)
+{
+    if (!t || !sink) return ADSB_AMD_EINVAL;
+    t->sink = sink;
+    t->user = user;
+    try
+    {
+        t->impl.Start(t);
+    } catch (...)
+    {
+        return ADSB_AMD_EINVAL;
+    }
+    return ADSB_AMD_OK;
+}
+extern "C" int adsb_amd_transport_stop(adsb_amd_transport_t* t)
+{
+    if (!t) return ADSB_AMD_EINVAL;
+    t->impl.Stop();
+    return ADSB_AMD_OK;
+}
+extern "C" int adsb_amd_transport_push(adsb_amd_transport_t* t, const uint8_t* data, size_t nbytes)
+{
+    if (!t || (!data && nbytes)) return ADSB_AMD_EINVAL;
+    try
+    {
+        t->impl.Push(data, nbytes);
+    } catch (...)
+    {
+        return ADSB_AMD_EINVAL;
+    }
+    return ADSB_AMD_OK;
+}
+extern "C" int adsb_amd_transport_stats(const adsb_amd_transport_t* t, uint64_t* delivered, int* producer_done, int* page_locked)
+{
+    if (!t) return ADSB_AMD_EINVAL;
+    if (delivered) *delivered = t->impl.Delivered();
+    if (producer_done) *producer_done = t->impl.ProducerDone() ? 1 : 0;
+    if (page_locked) *page_locked = t->impl.PageLocked() ? 1 : 0;
+    return ADSB_AMD_OK;
+}
+
+extern "C" long adsb_amd_handler_run_replay(adsb_amd_handler_t* h, const char* path, adsb_amd_on_changed_fn cb, void* user, uint64_t* buffers,
+                                            double* seconds)
+{
+    if (!h || !path) return ADSB_AMD_EINVAL;
+    struct stat st;
+    if (stat(path, &st) != 0)
+    {
+        h->error = std::string("cannot open ") + path + ": " + strerror(errno);
+        return ADSB_AMD_EINVAL;
+    }
+    const uint64_t want = (uint64_t)st.st_size / adsb_amd::Transport::kBufferLength;
+    struct Sink final : adsb_amd::Transport::Sink
+    {
+        adsb_amd_handler_t*    h;
+        adsb_amd_on_changed_fn cb;
+        void*                  user;
+        long                   accepted = 0, failed = 0;
+        void Deliver(const uint8_t* data, size_t nbytes) override
+        { // RTLSDR::ConsumerThreadLoop -> IDataHandler::HandleData: one call, one independent buffer
+            const long rc = adsb_amd_handler_handle_data(h, data, nbytes, 0, cb, user);
+            if (rc < 0) failed = rc;
+            else accepted += rc;
+        }
+    } sink;
+    sink.h = h, sink.cb = cb, sink.user = user;
+    const auto t0 = std::chrono::steady_clock::now();
+    try
+    {
+        adsb_amd::Transport tr(path, false);
+        tr.Start(&sink);
+        while (tr.Delivered() < want && !sink.failed) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        tr.Stop();
+        if (buffers) *buffers = tr.Delivered();
+    } catch (const std::exception& e)
+    {
+        h->error = e.what();
+        return ADSB_AMD_EINVAL;
+    }
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return sink.failed ? sink.failed : sink.accepted;
+}

@@ -1,0 +1,164 @@
+// transport.cpp -- see transport.hpp.
+#include "transport.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <stdexcept>
+
+namespace adsb_amd
+{
+
+Transport::Transport(std::string replay_path, bool loop) : replay_path_(std::move(replay_path)), loop_(loop)
+{
+    const size_t bytes = kBufferCount * kBufferLength;
+    void*        p     = nullptr;
+    int          ndev  = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) page_locked_ = true;
+    else
+    {
+        (void)hipGetLastError();
+        p = std::aligned_alloc(4096, bytes);
+        if (!p) throw std::bad_alloc();
+    }
+    ring_ = static_cast<uint8_t*>(p);
+}
+
+Transport::~Transport()
+{
+    Stop();
+    if (page_locked_) (void)hipHostFree(ring_);
+    else std::free(ring_);
+}
+
+std::string Transport::ReplayFileFor(uint32_t frequency_hz)
+{
+    const auto path = std::filesystem::absolute(std::to_string(frequency_hz) + ".test.dat");
+    std::error_code ec;
+    return std::filesystem::exists(path, ec) ? path.string() : std::string{};
+}
+
+void Transport::Start(Sink* sink)
+{
+    if (started_.exchange(true)) return;
+    stop_requested_ = false;
+    producer_done_  = false;
+    sink_           = sink;
+    head_ = tail_ = 0;
+    if (Replaying())
+    {
+        const int probe = open(replay_path_.c_str(), O_RDONLY);
+        if (probe < 0)
+        {
+            started_ = false;
+            throw std::runtime_error("Cannot open test data file");
+        }
+        close(probe);
+        producer_ = std::thread([this]() { ReplayLoop(); });
+    }
+    consumer_ = std::thread([this]() { ConsumerLoop(); });
+}
+
+void Transport::Stop()
+{
+    if (!started_.exchange(false)) return;
+    stop_requested_ = true;
+    {
+        std::unique_lock lock(mutex_);
+        data_consumed_.notify_all();
+        data_available_.notify_all();
+    }
+    if (producer_.joinable()) producer_.join();
+    if (consumer_.joinable()) consumer_.join();
+}
+
+// One BufferLength read per iteration straight into the next free slot (the reference reads into a staging vector and copies,
+// RTLSDR.hpp:421-438; reading in place saves the copy and keeps its order and its sizes).
+void Transport::ReplayLoop()
+{
+    int fd = open(replay_path_.c_str(), O_RDONLY);
+    while (fd >= 0 && !stop_requested_)
+    {
+        size_t slot;
+        {
+            std::unique_lock lock(mutex_);
+            data_consumed_.wait(lock, [&]() { return HasSlot() || stop_requested_.load(); });
+            if (stop_requested_) break;
+            slot = tail_;
+        }
+        uint8_t* dst  = ring_ + slot * kBufferLength;
+        size_t   have = 0;
+        while (have < kBufferLength)
+        {
+            const ssize_t r = read(fd, dst + have, kBufferLength - have);
+            if (r <= 0) break;
+            have += (size_t)r;
+        }
+        if (have < kBufferLength)
+        { // end of the file (a trailing partial buffer is dropped): start over, or finish a one-pass replay
+            close(fd);
+            fd = -1;
+            if (!loop_) break;
+            fd = open(replay_path_.c_str(), O_RDONLY);
+            struct stat st;
+            if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < kBufferLength))
+            { // nothing deliverable in it: do not spin
+                close(fd);
+                fd = -1;
+            }
+            continue;
+        }
+        {
+            std::unique_lock lock(mutex_);
+            tail_ = (tail_ + 1) % kBufferCount;
+            data_available_.notify_one();
+        }
+    }
+    if (fd >= 0) close(fd);
+    producer_done_ = true;
+    std::unique_lock lock(mutex_);
+    data_available_.notify_all();
+}
+
+void Transport::Push(const uint8_t* data, size_t nbytes)
+{
+    if (nbytes % kBufferLength != 0) throw std::runtime_error("Data size mismatch");
+    for (size_t at = 0; at < nbytes; at += kBufferLength)
+    {
+        std::unique_lock lock(mutex_);
+        data_consumed_.wait(lock, [&]() { return HasSlot() || stop_requested_.load() || !started_.load(); });
+        if (stop_requested_ || !started_) return;
+        std::memcpy(ring_ + tail_ * kBufferLength, data + at, kBufferLength);
+        tail_ = (tail_ + 1) % kBufferCount;
+        data_available_.notify_one();
+    }
+}
+
+void Transport::ConsumerLoop()
+{
+    for (;;)
+    {
+        size_t slot;
+        {
+            std::unique_lock lock(mutex_);
+            data_available_.wait(lock, [&]() { return !Empty() || stop_requested_.load(); });
+            if (stop_requested_) return;
+            slot = head_;
+        }
+        sink_->Deliver(ring_ + slot * kBufferLength, kBufferLength);
+        delivered_.fetch_add(1);
+        {
+            std::unique_lock lock(mutex_);
+            head_ = (head_ + 1) % kBufferCount;
+            data_consumed_.notify_one();
+        }
+    }
+}
+
+} // namespace adsb_amd

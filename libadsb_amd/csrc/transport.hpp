@@ -1,0 +1,74 @@
+// transport.hpp -- the sample transport under the handlers, for the stand-alone build of the adapters.
+//
+// Inside a libadsb checkout the handlers own an RTLSDR object (reference RTLSDR.hpp) and nothing here is used.  Stand-alone there
+// is no librtlsdr, so this restates what that class does FOR A HANDLER and nothing else (no device manager, no USB):
+//   * a ring of BufferCount = 16 slots of BufferLength = 262144 bytes between one producer and one consumer thread, the producer
+//     blocking while the ring is full, the consumer handing one slot at a time to IDataHandler::HandleData and recycling it
+//     afterwards (RTLSDR.hpp:55-56, 493-539, 564-570);
+//   * the producer is the replay of "<frequency>.test.dat" in the working directory when that file exists -- whole BufferLength
+//     reads in file order, the file re-opened at its end, a trailing partial read never delivered (:396-442) -- or whoever calls
+//     push(), which is RTLSDR::OnDataAvailable (:493-510) for a host that owns the receiver (its USB callback, :549-555).
+// The slots are page-locked when a HIP runtime is usable (the handler's upload is then a DMA straight out of the slot) and plain
+// aligned memory otherwise; either way they are host memory that the handler only reads.
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <cstddef>
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <thread>
+
+namespace adsb_amd
+{
+
+class Transport
+{
+  public:
+    static constexpr size_t kBufferLength = size_t{65536u} * 4u; // RTLSDR::BufferLength
+    static constexpr size_t kBufferCount  = 16;                  // RTLSDR::BufferCount
+
+    struct Sink
+    {
+        virtual ~Sink()                                           = default;
+        virtual void Deliver(const uint8_t* data, size_t nbytes) = 0; // one slot; valid only during the call (RTLSDR.hpp:531-537)
+    };
+
+    // replay_path empty: push mode.  loop: re-open the file at its end like the reference (false: one pass, then the producer ends).
+    explicit Transport(std::string replay_path = {}, bool loop = true);
+    ~Transport();
+    Transport(Transport const&)            = delete;
+    Transport& operator=(Transport const&) = delete;
+
+    // "<frequency>.test.dat" in the working directory, or "" when there is none (RTLSDR.hpp:399-405)
+    static std::string ReplayFileFor(uint32_t frequency_hz);
+
+    bool     Replaying() const { return !replay_path_.empty(); }
+    void     Start(Sink* sink); // RTLSDR::Start (:444-474); throws std::runtime_error when the replay file cannot be opened
+    void     Stop();            // RTLSDR::Stop (:476-487) and the joins of ~RTLSDR (:541-546)
+    void     Push(const uint8_t* data, size_t nbytes); // RTLSDR::OnDataAvailable: throws std::runtime_error on a size that is not a multiple of BufferLength
+    uint64_t Delivered() const { return delivered_.load(); }
+    bool     ProducerDone() const { return producer_done_.load(); } // one-pass replay reached the end of the file
+    bool     PageLocked() const { return page_locked_; }
+
+  private:
+    void ReplayLoop();
+    void ConsumerLoop();
+    bool HasSlot() const { return ((tail_ + 1) % kBufferCount) != head_; }
+    bool Empty() const { return head_ == tail_; }
+
+    std::string             replay_path_;
+    bool                    loop_;
+    uint8_t*                ring_        = nullptr; // kBufferCount * kBufferLength bytes
+    bool                    page_locked_ = false;
+    size_t                  head_ = 0, tail_ = 0;
+    Sink*                   sink_ = nullptr;
+    std::thread             producer_, consumer_;
+    std::mutex              mutex_;
+    std::condition_variable data_available_, data_consumed_;
+    std::atomic<bool>       stop_requested_{false}, started_{false}, producer_done_{false};
+    std::atomic<uint64_t>   delivered_{0};
+};
+
+} // namespace adsb_amd

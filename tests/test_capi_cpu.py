@@ -198,3 +198,71 @@ def test_host_field_decoder_matches_the_oracle_stream_and_heading_margin(native_
             hd = int(math.atan2(float(e), float(n)) * 360 / (math.pi * 2))
             hd = hd + 360 if hd < 0 else hd
         assert (int(d["kind"]), int(d["a"]), int(d["b"])) == (A.K_VELOCITY, v, hd), (e, n, d)
+
+
+def test_transport_ring_replay_and_push(native_libs, tmp_path):
+    """The stand-alone transport (what RTLSDR gives a handler, RTLSDR.hpp:396-442, 493-539): a recording is delivered in whole
+    262144-byte buffers in file order, the trailing partial read never; the ring holds 15 undelivered buffers and then blocks the
+    producer; push() refuses sizes that are not a multiple of the buffer length (RTLSDR.hpp:495)."""
+    import threading
+    import time
+    rng = np.random.default_rng(42)
+    data = rng.integers(0, 256, size=20 * BB + 12345, dtype=np.uint8)
+    path = tmp_path / "1090000000.test.dat"
+    data.tofile(path)
+    got = []
+    t = A.Transport(str(path), loop=False)
+    t.start(got.append)
+    for _ in range(2000):
+        if t.stats()["delivered"] >= 20:
+            break
+        time.sleep(0.005)
+    t.stop()
+    assert len(got) == 20 and t.stats()["producer_done"]
+    assert b"".join(got) == data[:20 * BB].tobytes()
+    t.close()
+    # looping replay: the file is re-opened at its end, like the reference's TestDataReadLoop
+    got = []
+    t = A.Transport(str(path), loop=True)
+    t.start(got.append)
+    for _ in range(2000):
+        if t.stats()["delivered"] >= 45:
+            break
+        time.sleep(0.005)
+    t.stop()
+    n = len(got)
+    assert n >= 45 and all(got[i] == data[(i % 20) * BB:(i % 20 + 1) * BB].tobytes() for i in range(n))
+    t.close()
+    with pytest.raises(A.AdsbAmdError):
+        A.Transport(str(tmp_path / "missing.dat")).start(got.append)
+    # push mode with a slow consumer: the producer blocks once 15 slots are waiting, nothing is lost or reordered
+    got, gate = [], threading.Event()
+
+    def slow(b):
+        gate.wait()
+        got.append(b)
+    t = A.Transport()
+    t.start(slow)
+    blocks = [rng.integers(0, 256, size=BB, dtype=np.uint8) for _ in range(40)]
+    done = threading.Event()
+
+    def producer():
+        t.push(np.concatenate(blocks[:24]))  # several buffers in one call, as a USB callback may deliver them
+        for b in blocks[24:]:
+            t.push(b)
+        done.set()
+    th = threading.Thread(target=producer)
+    th.start()
+    time.sleep(0.3)
+    assert not done.is_set(), "the producer must be blocked on a full ring"
+    gate.set()
+    th.join(timeout=30)
+    for _ in range(2000):
+        if len(got) == 40:
+            break
+        time.sleep(0.005)
+    t.stop()
+    assert [bytes(g) for g in got] == [b.tobytes() for b in blocks]
+    with pytest.raises(A.AdsbAmdError):
+        t.push(np.zeros(BB + 2, dtype=np.uint8))
+    t.close()

@@ -457,3 +457,33 @@ def test_resolver_on_gpu_decoded_fields_equals_oracle(scanner):
     ofr, oac = H.oracle_run(iq, BB)
     H.assert_streams_equal(fr, ac, ofr, oac)
     assert H.callback_text(ac) == H.callback_text(oac) and n == len(ofr) > 1000
+
+
+def test_replay_through_the_ring_and_the_production_factory(native_libs, tmp_path):
+    """libadsb's replay mode (RTLSDR.hpp:396-442): (1) adsb_amd_handler_run_replay -- the recording through the 16-slot ring, one
+    HandleData per slot on the consumer thread -- gives the oracle's stream; (2) the PRODUCTION factory ADSB::TryCreateADSB1090Handler
+    (ADSB.h:13-15), started the way DataProviderImpl starts it, finds "1090000000.test.dat" in the working directory, replays it
+    and delivers the same callback lines; Stop / Start / Stop works."""
+    import subprocess
+    from libadsb_amd import build
+    iq, _ = synth.fill_range(900, 24)
+    path = tmp_path / "1090000000.test.dat"
+    with open(path, "wb") as f:
+        f.write(iq.tobytes())
+        f.write(iq[:7777].tobytes())
+    h = A.Handler1090()
+    n, fr, ac, nbuf, sec = h.run_replay(str(path))
+    ofr, oac = H.oracle_run(iq, BB)
+    assert nbuf == 24 and n == len(ofr) > 1000
+    ofr = ofr.copy()
+    ofr["offset"] %= BB // 2  # every slot is its own HandleData call: frame offsets count from the start of that call
+    H.assert_streams_equal(fr, ac, ofr, oac)
+    h.close()
+    exe = build.build_cxx_test()
+    o = O.Oracle1090(sample_clock_hz=0)  # wall clock, like the C++ handler and the reference
+    _, oac = H.oracle_run(iq, BB, oracle=o)
+    want = [t.encode("latin-1") for t in H.callback_text(oac)]
+    out = subprocess.run([exe, "--provider", str(len(want))], capture_output=True, timeout=180, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    got = [l for l in out.stdout.split(b"\n") if l and not l.startswith(b"/opt/amdgpu")]
+    assert got == want
