@@ -48,6 +48,10 @@ def parse_args(argv=None):
                     "scan); used for rocprofv3 runs, where the runtime's shader-based copy would otherwise co-run with the scan kernel")
     ap.add_argument("--workload", choices=["1090", "uat978"], default="1090", help="1090: the headline metric (BASELINE configs[1]+[2], and "
                     "configs[3] when --gpus > 1); uat978: BASELINE configs[4] alone, one independent stream per GPU (replicas only)")
+    ap.add_argument("--rate", type=int, choices=[20, 24], default=20, help="samples per microsecond x 10 of the synthetic input.  20: the reference's "
+                    "rate (parity-green).  24: the same pulse trains sampled at 2.4 MS/s -- BASELINE.json quotes that rate, but nothing in the "
+                    "reference demodulates it (SURVEY.md F3/F5): the 2-samples-per-microsecond kernel scans those bytes as a THROUGHPUT-ONLY "
+                    "workload (same bytes per sample, same kernels; the records it finds are chance matches and are not checked)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the end_to_end and uat978 blocks (profiling runs)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N > 1 ranks all on cuda:0 with the gloo backend: exercises the "
                     "multi-rank code path (sharding, record gather, resolve) on a one-GPU box; the numbers mean nothing")
@@ -210,13 +214,16 @@ def bench_1090_single(args, local_rank, A, synth, torch):
     BB = A.REF_BUFFER_BYTES
     nbuf = (args.mib << 20) // BB
     ncpu = max(1, len(os.sched_getaffinity(0)))
-    iq_host, injected = synth.fill_range(0, nbuf, nthreads=ncpu)
+    iq_host, injected = synth.fill_range(0, nbuf, nthreads=ncpu, rate_x10=args.rate)
     d_iq = torch.from_numpy(iq_host).cuda()
     torch.cuda.synchronize()
     sc = A.Scanner(local_rank)
     stream = torch.cuda.current_stream().cuda_stream
     nbytes = d_iq.numel()
     run = make_runner(args, sc, d_iq, BB, stream)
+    if args.rate != 20:
+        args.no_extras = True  # end-to-end and CPU legs are defined on the parity-green workload only
+        args.cpu_buffers = 0
 
     # Set-up, not measurement: the first scans fault in the record regions (512 MiB of address space, touched where
     # used) and the clocks ramp up from idle; both are one-off costs of a long-running demodulator.  SETUP_STEPS untimed
@@ -249,7 +256,11 @@ def bench_1090_single(args, local_rank, A, synth, torch):
         "value": round(samples * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "setup_steps": SETUP_STEPS, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8 in / u16 integer (bit-exact)", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]+[2]: " + WORKLOAD_1090 % (args.mib, nbuf),
+        "config": {"workload": ("BASELINE configs[1]+[2]: " + WORKLOAD_1090 % (args.mib, nbuf)) if args.rate == 20 else
+                               ("THROUGHPUT ONLY, parity unpinned: %d MiB synthetic u8 IQ sampled at 2.4 MS/s (the generator's pulse trains integrated over "
+                                "1/2.4 us bins, frames at random sub-sample offsets, SURVEY.md section 8d) scanned by the 2-samples-per-microsecond "
+                                "kernel; no 2.4 MS/s demodulator exists in the reference (F3/F5) nor here yet, the records are chance matches" % args.mib),
+                   "sample_rate_x10": args.rate,
                    "bytes_per_gpu": nbytes, "buffers_per_gpu": nbuf, "sharding": "one GPU", "pipelined": not args.serial},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(nbytes),
@@ -268,6 +279,25 @@ def bench_1090_single(args, local_rank, A, synth, torch):
     }
     if not args.no_extras:
         out["end_to_end"] = end_to_end_1090(A, rec, dec, iq_host, BB, nbuf, accepted)
+        # the "2.4 MS/s" flavour of the same configuration (BASELINE.json's wording): throughput only, see --rate
+        try:
+            iq24, _ = synth.fill_range(0, nbuf, nthreads=ncpu, rate_x10=24)
+            d24 = torch.from_numpy(iq24).cuda()
+            run24 = make_runner(args, sc, d24, BB, stream)
+            run24(10)
+            torch.cuda.synchronize()
+            t24 = time.perf_counter()
+            (r24, _), k24, _ = run24(50)
+            torch.cuda.synchronize()
+            e24 = time.perf_counter() - t24
+            out["rate_2p4_throughput_only"] = {
+                "value": round(samples * 50 / e24 / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(e24 / 50 * 1e3, 4), "kernel_ms": round(k24 / 50, 4),
+                "roofline_frac": round((2.0 * samples + 32.0 * len(r24)) / (k24 / 50 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "records_per_step": int(len(r24)),
+                "note": "1 GiB of the generator's pulse trains sampled at 2.4 MS/s, scanned by the 2-samples-per-microsecond kernel: parity unpinned, "
+                        "no reference demodulator for this rate exists (SURVEY.md F3/F5); records are chance matches"}
+            del d24, iq24
+        except Exception as e:
+            out["rate_2p4_throughput_only"] = {"error": repr(e)}
     if args.cpu_buffers > 0:
         out["cpu_baseline"] = cpu_baseline(iq_host, min(args.cpu_buffers, nbuf), BB)
     sc.close()

@@ -218,7 +218,10 @@ static int build_frame(const adsb_synth_cfg_t* c, uint64_t* rs, uint64_t buf_ind
 
 static inline uint8_t clamp_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
-int adsb_synth_fill(const adsb_synth_cfg_t* c, uint64_t buf_index, uint8_t* out, size_t nbytes, adsb_synth_frame_t* frames, int cap)
+/* rate_x10: samples per microsecond times ten.  20 = the reference's 2 samples per microsecond (one pulse = one sample, ADSB1090.cpp:749-771).
+ * 24 = the same pulse train (0.5 us pulses) integrated over sample bins of 1/2.4 us, the frame starting at a random fraction of a
+ * sample: what a 2.4 MS/s receiver delivers.  Nothing in the reference demodulates that rate; it is a throughput workload. */
+static int fill_impl(const adsb_synth_cfg_t* c, uint64_t buf_index, uint8_t* out, size_t nbytes, adsb_synth_frame_t* frames, int cap, int rate_x10)
 {
     const size_t n = nbytes / 2;
     /* ---- background: I,Q = 127 + u, u uniform integer in [-A, +A] (16-bit multiply-shift per draw) */
@@ -267,20 +270,48 @@ int adsb_synth_fill(const adsb_synth_cfg_t* c, uint64_t buf_index, uint8_t* out,
         double cphi  = cos(phi), sphi = sin(phi);
         int    nsamp = (8 + nbits) * 2;
 
-        float level[260];
+        float level[300];
         memset(level, 0, sizeof(level));
         static const int pre[4] = {0, 2, 7, 9};
-        for (int p = 0; p < 4; p++)
+        if (rate_x10 == 20)
         {
-            if (half) { level[pre[p]] += 0.5f; level[pre[p] + 1] += 0.5f; }
-            else level[pre[p]] += 1.0f;
+            for (int p = 0; p < 4; p++)
+            {
+                if (half) { level[pre[p]] += 0.5f; level[pre[p] + 1] += 0.5f; }
+                else level[pre[p]] += 1.0f;
+            }
+            for (int b = 0; b < nbits; b++)
+            {
+                int bit = (msg[b >> 3] >> (7 - (b & 7))) & 1;
+                int at  = 16 + 2 * b + (bit ? 0 : 1);
+                if (half) { level[at] += 0.5f; level[at + 1] += 0.5f; }
+                else level[at] += 1.0f;
+            }
         }
-        for (int b = 0; b < nbits; b++)
-        {
-            int bit = (msg[b >> 3] >> (7 - (b & 7))) & 1;
-            int at  = 16 + 2 * b + (bit ? 0 : 1);
-            if (half) { level[at] += 0.5f; level[at + 1] += 0.5f; }
-            else level[at] += 1.0f;
+        else
+        { /* half-microsecond slot k of the frame carries a pulse or not; slot k spans [k/2, (k+1)/2) us after the frame start, which
+             lies `frac` of a sample into sample 0.  Each sample integrates what falls into its bin. */
+            const double spu  = rate_x10 / 10.0;                                  /* samples per microsecond */
+            const double frac = (half ? 0.5 : 0.0) + (double)sm64_below(&fs, 5) / 5.0 * 0.5; /* 0 .. 0.9 sample */
+            nsamp             = (int)((8 + nbits) * spu + frac) + 2;
+            for (int k = 0; k < (8 + nbits) * 2; k++)
+            {
+                int on;
+                if (k < 16) on = (k == pre[0] || k == pre[1] || k == pre[2] || k == pre[3]);
+                else
+                {
+                    int b   = (k - 16) >> 1;
+                    int bit = (msg[b >> 3] >> (7 - (b & 7))) & 1;
+                    on      = ((k & 1) == 0) ? bit : !bit;
+                }
+                if (!on) continue;
+                const double t0 = frac + k * 0.5 * spu, t1 = t0 + 0.5 * spu; /* in samples */
+                for (int sidx = (int)t0; sidx < 299 && (double)sidx < t1; sidx++)
+                {
+                    double lo = t0 > sidx ? t0 : sidx, hi = t1 < sidx + 1 ? t1 : sidx + 1;
+                    if (hi > lo) level[sidx] += (float)(hi - lo);
+                }
+            }
         }
         for (int s = 0; s < nsamp + 1 && pos + (size_t)s < n; s++)
         {
@@ -306,6 +337,15 @@ int adsb_synth_fill(const adsb_synth_cfg_t* c, uint64_t buf_index, uint8_t* out,
     return nframes;
 }
 
+int adsb_synth_fill(const adsb_synth_cfg_t* c, uint64_t buf_index, uint8_t* out, size_t nbytes, adsb_synth_frame_t* frames, int cap)
+{
+    return fill_impl(c, buf_index, out, nbytes, frames, cap, 20);
+}
+int adsb_synth_fill_rate(const adsb_synth_cfg_t* c, uint64_t buf_index, uint8_t* out, size_t nbytes, adsb_synth_frame_t* frames, int cap, int rate_x10)
+{
+    return fill_impl(c, buf_index, out, nbytes, frames, cap, rate_x10 == 24 ? 24 : 20);
+}
+
 typedef struct
 {
     const adsb_synth_cfg_t* cfg;
@@ -314,17 +354,27 @@ typedef struct
     size_t                  buf_bytes;
     int                     tid, nthreads;
     long                    frames;
+    int                     rate_x10;
 } fill_job_t;
 
 static void* fill_worker(void* p)
 {
     fill_job_t* j = (fill_job_t*)p;
     for (uint64_t b = (uint64_t)j->tid; b < j->count; b += (uint64_t)j->nthreads)
-        j->frames += adsb_synth_fill(j->cfg, j->first + b, j->out + b * j->buf_bytes, j->buf_bytes, NULL, 0);
+        j->frames += fill_impl(j->cfg, j->first + b, j->out + b * j->buf_bytes, j->buf_bytes, NULL, 0, j->rate_x10);
     return NULL;
 }
 
+static long fill_range_impl(const adsb_synth_cfg_t* c, uint64_t first_buf, uint64_t nbuf, uint8_t* out, size_t buf_bytes, int nthreads, int rate_x10);
 long adsb_synth_fill_range(const adsb_synth_cfg_t* c, uint64_t first_buf, uint64_t nbuf, uint8_t* out, size_t buf_bytes, int nthreads)
+{
+    return fill_range_impl(c, first_buf, nbuf, out, buf_bytes, nthreads, 20);
+}
+long adsb_synth_fill_range_rate(const adsb_synth_cfg_t* c, uint64_t first_buf, uint64_t nbuf, uint8_t* out, size_t buf_bytes, int nthreads, int rate_x10)
+{
+    return fill_range_impl(c, first_buf, nbuf, out, buf_bytes, nthreads, rate_x10 == 24 ? 24 : 20);
+}
+static long fill_range_impl(const adsb_synth_cfg_t* c, uint64_t first_buf, uint64_t nbuf, uint8_t* out, size_t buf_bytes, int nthreads, int rate_x10)
 {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 64) nthreads = 64;
@@ -332,7 +382,7 @@ long adsb_synth_fill_range(const adsb_synth_cfg_t* c, uint64_t first_buf, uint64
     fill_job_t jobs[64];
     for (int t = 0; t < nthreads; t++)
     {
-        jobs[t] = (fill_job_t){c, first_buf, nbuf, out, buf_bytes, t, nthreads, 0};
+        jobs[t] = (fill_job_t){c, first_buf, nbuf, out, buf_bytes, t, nthreads, 0, rate_x10};
         pthread_create(&th[t], NULL, fill_worker, &jobs[t]);
     }
     long total = 0;

@@ -38,6 +38,11 @@ int  adsb_synth_fill(const adsb_synth_cfg_t* cfg, uint64_t buf_index, uint8_t* o
 /* Fill nbuf consecutive buffers with nthreads worker threads.  Returns total frames injected. */
 long adsb_synth_fill_range(const adsb_synth_cfg_t* cfg, uint64_t first_buf, uint64_t nbuf, uint8_t* out, size_t buf_bytes, int nthreads);
 
+/* The same with a sample rate: rate_x10 = 20 (2.0 MS/s, identical bytes to the functions above) or 24 (2.4 MS/s: the pulse train
+ * integrated over 1/2.4 us bins, frames at random sub-sample offsets; a throughput workload, nothing in the reference decodes it). */
+int  adsb_synth_fill_rate(const adsb_synth_cfg_t* cfg, uint64_t buf_index, uint8_t* out, size_t nbytes, adsb_synth_frame_t* frames, int cap, int rate_x10);
+long adsb_synth_fill_range_rate(const adsb_synth_cfg_t* cfg, uint64_t first_buf, uint64_t nbuf, uint8_t* out, size_t buf_bytes, int nthreads, int rate_x10);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,9 @@ def lib():
         L.adsb_synth_fill.argtypes = [C.POINTER(SynthCfg), C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.adsb_synth_fill_range.argtypes = [C.POINTER(SynthCfg), C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int]
         L.adsb_synth_fill_range.restype = C.c_long
+        L.adsb_synth_fill_range_rate.argtypes = [C.POINTER(SynthCfg), C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+        L.adsb_synth_fill_range_rate.restype = C.c_long
+        L.adsb_synth_fill_rate.argtypes = [C.POINTER(SynthCfg), C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
         L.adsb_synth_pool_addr.argtypes = [C.POINTER(SynthCfg), C.c_uint32]
         L.adsb_synth_pool_addr.restype = C.c_uint32
         L.adsb_synth978_default.argtypes = [C.POINTER(Synth978Cfg)]
@@ -75,13 +78,16 @@ def fill(buf_index, nbytes=BUFFER_BYTES, cfg=None, manifest=False):
     return out
 
 
-def fill_range(first_buf, nbuf, buf_bytes=BUFFER_BYTES, cfg=None, nthreads=None, out=None):
-    """Returns (uint8 array of nbuf*buf_bytes, frames injected)."""
+def fill_range(first_buf, nbuf, buf_bytes=BUFFER_BYTES, cfg=None, nthreads=None, out=None, rate_x10=20):
+    """Returns (uint8 array of nbuf*buf_bytes, frames injected).  rate_x10 = 24: the same pulse trains sampled at 2.4 MS/s."""
     cfg = cfg or default_cfg()
     if out is None:
         out = np.empty(nbuf * buf_bytes, dtype=np.uint8)
     nthreads = nthreads or min(32, os.cpu_count() or 1)
-    n = lib().adsb_synth_fill_range(C.byref(cfg), first_buf, nbuf, out.ctypes.data, buf_bytes, nthreads)
+    if rate_x10 == 20:
+        n = lib().adsb_synth_fill_range(C.byref(cfg), first_buf, nbuf, out.ctypes.data, buf_bytes, nthreads)
+    else:
+        n = lib().adsb_synth_fill_range_rate(C.byref(cfg), first_buf, nbuf, out.ctypes.data, buf_bytes, nthreads, rate_x10)
     return out, n
 
 

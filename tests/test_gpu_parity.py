@@ -487,3 +487,26 @@ def test_replay_through_the_ring_and_the_production_factory(native_libs, tmp_pat
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     got = [l for l in out.stdout.split(b"\n") if l and not l.startswith(b"/opt/amdgpu")]
     assert got == want
+
+
+def test_random_generator_settings_slice(scanner):
+    """A slice of the wide sweep (tools/fuzz_many.py: thousands of settings on an MI355X, result under profiles/): 120 random
+    generator settings (noise 0..49, dense to empty bands, weak to saturating amplitudes, any mix of DF17 / DF11 / AP-type, bit
+    flips, half-sample offsets), three buffers each: records == the C restatement of the emission contract over the oracle's
+    probes, and the handler's callback stream == the oracle's sequential loop."""
+    rng = np.random.default_rng(20260104)
+    for k in range(120):
+        cfg = synth.default_cfg(noise_amp=int(rng.integers(0, 50)), mean_spacing=int(rng.choice([0, 250, 600, 2000, 20000])),
+                                amp_lo=int(rng.integers(5, 100)), amp_hi=int(rng.integers(100, 129)), pct_df17=int(rng.integers(0, 60)),
+                                pct_df11=int(rng.integers(0, 40)), pct_bitflip=int(rng.integers(0, 100)), pct_halfsample=int(rng.integers(0, 100)))
+        first = int(rng.integers(0, 10**6))
+        iq, _ = synth.fill_range(first, 3, cfg=cfg)
+        try:
+            H.assert_records_equal(scanner.scan(iq, BB), O.expected_records(iq, BB, dtype=A.RECORD_DTYPE, nthreads=3))
+            h = A.Handler1090()
+            fr, ac = h.handle_data(iq, BB)
+            h.close()
+            ofr, oac = H.oracle_run(iq, BB)
+            H.assert_streams_equal(fr, ac, ofr, oac)
+        except AssertionError as e:
+            raise AssertionError("setting %d first_buffer=%d %s: %s" % (k, first, {f[0]: getattr(cfg, f[0]) for f in cfg._fields_}, e))

@@ -321,3 +321,25 @@ def test_handle_data_one_large_call(native_libs):
         assert got == want and len(want) > 3000
         assert u.stream_state() == o.stream_state()
         u.close()
+
+
+def test_random_generator_settings_and_call_sizes_slice(native_libs):
+    """A slice of the wide sweep (tools/fuzz_many.py): 60 random UAT generator settings, the stream cut into random HandleData
+    calls, both carry modes: frames and stream state == the oracle after every call."""
+    rng = np.random.default_rng(9780104)
+    BBL = 262144
+    for k in range(60):
+        cfg = synth.default_cfg978(noise_amp=int(rng.integers(0, 30)), amp_lo=int(rng.integers(3, 40)), amp_hi=int(rng.integers(40, 120)),
+                                   mean_gap_bits=int(rng.choice([0, 30, 300, 3000, 50000])), pct_uplink=int(rng.integers(0, 100)),
+                                   pct_long=int(rng.integers(0, 100)), pct_corrupt=int(rng.integers(0, 100)), max_bad_bytes=int(rng.integers(1, 16)))
+        iq = synth.fill978(int(rng.integers(0, 10**6)), 3 * BBL, cfg)
+        full = bool(rng.integers(0, 2))
+        uu, oo = A.Uat978(carry_full=full), O.Oracle978(carry_full=full)
+        pos = 0
+        while pos < iq.size:
+            n = int(rng.choice([BBL, BBL, 2 * BBL, 65536, 30000, 100002]))
+            part = iq[pos:pos + n]
+            assert uu.handle_data(part) == oo.handle_data(part), (k, pos, {f[0]: getattr(cfg, f[0]) for f in cfg._fields_})
+            assert uu.stream_state() == oo.stream_state()
+            pos += n
+        uu.close()
