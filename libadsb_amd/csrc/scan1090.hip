@@ -658,6 +658,10 @@ __device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWin
 #ifndef ADSB_AMD_MIN_WAVES
 #define ADSB_AMD_MIN_WAVES 4
 #endif
+// Profiling builds only (tools/parts.sh): 1 = window load + s, 2 = + stage 1, 3 = + survivor queue and stage 2, 4 = everything.
+#ifndef ADSB_AMD_PARTS
+#define ADSB_AMD_PARTS 4
+#endif
 __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow)
 {
     // the interleaved image of s (scan1090.h), the slot of the sample in front of the chunk, then the survivor queue.  The queue
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         // and max(s_a, s_a+2) is one shared array (used at a = 1, 4 and 6).
         uint32_t surv32[2] = {0u, 0u};
 #pragma unroll
-        for (int b = 0; b < kHalfChunk / 512; b++)
+        for (int b = 0; b < (ADSB_AMD_PARTS >= 2 ? kHalfChunk / 512 : 0); b++)
         {
             uint32_t        T[17];
             const uint32_t* p  = &tile32[b * 512 + 8 * lane];
@@ -808,7 +812,8 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         e.base  = reinterpret_cast<uint4*>(a.chunk_records + (uint64_t)me * a.cap);
         e.cap   = a.cap;
         e.count = 0;
-        for (uint32_t base = 0; base < n1; base += (uint32_t)kQueueCap)
+        if (ADSB_AMD_PARTS < 3) e.count = (n1 == 0xFFFFFFFFu) ? 1u : 0u; // part builds: keep what was computed alive, emit nothing
+        for (uint32_t base = 0; ADSB_AMD_PARTS >= 3 && base < n1; base += (uint32_t)kQueueCap)
         {
             {
                 uint64_t sv  = surv;
@@ -879,8 +884,9 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
             }
             wave_lds_fence();
 
+            if (ADSB_AMD_PARTS < 4) e.count += (n2 == 0xFFFFFFFFu) ? 1u : 0u;
             // demodulate the candidates, one at a time, whole wave each
-            for (uint32_t t = 0; t < n2; t++)
+            for (uint32_t t = 0; ADSB_AMD_PARTS >= 4 && t < n2; t++)
             {
                 const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)queue[t]);
                 const Win      w   = make_win(pos);
