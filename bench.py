@@ -48,10 +48,10 @@ def parse_args(argv=None):
                     "scan); used for rocprofv3 runs, where the runtime's shader-based copy would otherwise co-run with the scan kernel")
     ap.add_argument("--workload", choices=["1090", "uat978"], default="1090", help="1090: the headline metric (BASELINE configs[1]+[2], and "
                     "configs[3] when --gpus > 1); uat978: BASELINE configs[4] alone, one independent stream per GPU (replicas only)")
-    ap.add_argument("--rate", type=int, choices=[20, 24], default=20, help="samples per microsecond x 10 of the synthetic input.  20: the reference's "
-                    "rate (parity-green).  24: the same pulse trains sampled at 2.4 MS/s -- BASELINE.json quotes that rate, but nothing in the "
-                    "reference demodulates it (SURVEY.md F3/F5): the 2-samples-per-microsecond kernel scans those bytes as a THROUGHPUT-ONLY "
-                    "workload (same bytes per sample, same kernels; the records it finds are chance matches and are not checked)")
+    ap.add_argument("--rate", type=int, choices=[20, 24], default=20, help="samples per microsecond x 10.  20: the reference's demodulator "
+                    "(parity-green, the headline).  24: the library's own 2.4 MS/s mode (ADSB_AMD_MODE_2400) on the same pulse trains sampled at "
+                    "2.4 MS/s -- BASELINE.json quotes that rate, nothing in the reference demodulates it (SURVEY.md F3/F5): parity unpinned, "
+                    "the kernel is checked against its specification oracle/oracle2400.c")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the end_to_end and uat978 blocks (profiling runs)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N > 1 ranks all on cuda:0 with the gloo backend: exercises the "
                     "multi-rank code path (sharding, record gather, resolve) on a one-GPU box; the numbers mean nothing")
@@ -217,7 +217,7 @@ def bench_1090_single(args, local_rank, A, synth, torch):
     iq_host, injected = synth.fill_range(0, nbuf, nthreads=ncpu, rate_x10=args.rate)
     d_iq = torch.from_numpy(iq_host).cuda()
     torch.cuda.synchronize()
-    sc = A.Scanner(local_rank)
+    sc = A.Scanner(local_rank, mode=args.rate)
     stream = torch.cuda.current_stream().cuda_stream
     nbytes = d_iq.numel()
     run = make_runner(args, sc, d_iq, BB, stream)
@@ -246,7 +246,7 @@ def bench_1090_single(args, local_rank, A, synth, torch):
     # host half on the records of one step: accepted frames -> msgs/s (no listener; with a native counting listener: end_to_end)
     resolve_s = 1e9
     for _ in range(5):  # best of 5: a few milliseconds of single-thread host work
-        res = A.Resolver()
+        res = A.Resolver(mode=args.rate, sample_clock_hz=100000 * args.rate)
         t1 = time.perf_counter()
         accepted, _, _ = res.feed(rec, BB // 2, nbuf, collect=False, decoded=dec)
         resolve_s = min(resolve_s, time.perf_counter() - t1)
@@ -257,14 +257,15 @@ def bench_1090_single(args, local_rank, A, synth, torch):
         "setup_steps": SETUP_STEPS, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8 in / u16 integer (bit-exact)", "data": "synthetic",
         "config": {"workload": ("BASELINE configs[1]+[2]: " + WORKLOAD_1090 % (args.mib, nbuf)) if args.rate == 20 else
-                               ("THROUGHPUT ONLY, parity unpinned: %d MiB synthetic u8 IQ sampled at 2.4 MS/s (the generator's pulse trains integrated over "
-                                "1/2.4 us bins, frames at random sub-sample offsets, SURVEY.md section 8d) scanned by the 2-samples-per-microsecond "
-                                "kernel; no 2.4 MS/s demodulator exists in the reference (F3/F5) nor here yet, the records are chance matches" % args.mib),
+                               ("PARITY UNPINNED (no reference demodulates this rate, SURVEY.md F3/F5): %d MiB synthetic u8 IQ sampled at 2.4 MS/s (the "
+                                "generator's pulse trains integrated over 1/2.4 us bins, frames at random sub-sample offsets) through the library's "
+                                "2.4 MS/s mode: packed gate, five-phase preamble correlation, overlap-weighted Manchester slicing, CRC-24 + 1-bit "
+                                "repair; kernel == oracle/oracle2400.c in the GPU tests" % args.mib),
                    "sample_rate_x10": args.rate,
                    "bytes_per_gpu": nbytes, "buffers_per_gpu": nbuf, "sharding": "one GPU", "pipelined": not args.serial},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(nbytes),
-                     "kernel": "scan1090_kernel", "kernel_ms": round(kernel_ms, 4),
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(nbytes) if args.rate == 20 else None,
+                     "kernel": "scan1090_kernel" if args.rate == 20 else "scan2400_kernel", "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes": int(alg_bytes)},
         "records_per_step": nrec, "frames_injected": injected,
         "decoded_msgs_per_step_rank0": int(accepted),
@@ -279,25 +280,31 @@ def bench_1090_single(args, local_rank, A, synth, torch):
     }
     if not args.no_extras:
         out["end_to_end"] = end_to_end_1090(A, rec, dec, iq_host, BB, nbuf, accepted)
-        # the "2.4 MS/s" flavour of the same configuration (BASELINE.json's wording): throughput only, see --rate
+        # the "2.4 MS/s" flavour of the same configuration (BASELINE.json's wording): the library's own mode for that rate, see --rate
         try:
-            iq24, _ = synth.fill_range(0, nbuf, nthreads=ncpu, rate_x10=24)
+            iq24, inj24 = synth.fill_range(0, nbuf, nthreads=ncpu, rate_x10=24)
             d24 = torch.from_numpy(iq24).cuda()
-            run24 = make_runner(args, sc, d24, BB, stream)
+            sc24 = A.Scanner(local_rank, mode=A.MODE_2400)
+            run24 = make_runner(args, sc24, d24, BB, stream)
             run24(10)
             torch.cuda.synchronize()
             t24 = time.perf_counter()
-            (r24, _), k24, _ = run24(50)
+            (r24, d24dec), k24, _ = run24(50)
             torch.cuda.synchronize()
             e24 = time.perf_counter() - t24
-            out["rate_2p4_throughput_only"] = {
-                "value": round(samples * 50 / e24 / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(e24 / 50 * 1e3, 4), "kernel_ms": round(k24 / 50, 4),
-                "roofline_frac": round((2.0 * samples + 32.0 * len(r24)) / (k24 / 50 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "records_per_step": int(len(r24)),
-                "note": "1 GiB of the generator's pulse trains sampled at 2.4 MS/s, scanned by the 2-samples-per-microsecond kernel: parity unpinned, "
-                        "no reference demodulator for this rate exists (SURVEY.md F3/F5); records are chance matches"}
+            r24, d24dec = r24.copy(), d24dec.copy()
+            res24 = A.Resolver(mode=A.MODE_2400, sample_clock_hz=2400000)
+            acc24, _, _ = res24.feed(r24, BB // 2, nbuf, collect=False, decoded=d24dec)
+            out["mode_2400"] = {
+                "value": round(samples * 50 / e24 / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(e24 / 50 * 1e3, 4), "kernel": "scan2400_kernel",
+                "kernel_ms": round(k24 / 50, 4), "roofline_frac": round((2.0 * samples + 32.0 * len(r24)) / (k24 / 50 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "records_per_step": int(len(r24)), "frames_injected": int(inj24), "accepted_frames": int(acc24),
+                "note": "PARITY UNPINNED: 1 GiB of the generator's pulse trains sampled at 2.4 MS/s through ADSB_AMD_MODE_2400 (specification "
+                        "oracle/oracle2400.c; no reference demodulator for this rate exists, SURVEY.md F3/F5); first version of the kernel, not tuned"}
+            sc24.close()
             del d24, iq24
         except Exception as e:
-            out["rate_2p4_throughput_only"] = {"error": repr(e)}
+            out["mode_2400"] = {"error": repr(e)}
     if args.cpu_buffers > 0:
         out["cpu_baseline"] = cpu_baseline(iq_host, min(args.cpu_buffers, nbuf), BB)
     sc.close()

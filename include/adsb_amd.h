@@ -120,6 +120,15 @@ typedef struct adsb_amd_ctx adsb_amd_ctx_t;
 /* The demodulating part of ADSB1090Handler (constructed at ADSB1090.cpp:144-154): what HandleData (:158-175) -> DetectModeS
  * (:741-959) computes from the samples alone.  device < 0: current HIP device. */
 int         adsb_amd_create(adsb_amd_ctx_t** out, int device);
+/* The same with an explicit scan mode.  ADSB_AMD_MODE_2000: the reference's demodulator, 2 samples per microsecond
+ * (ADSB1090.cpp:148, 741-959) -- what adsb_amd_create gives.  ADSB_AMD_MODE_2400: a second mode for receivers run at 2.4 MS/s, the
+ * rate BASELINE.json quotes; libadsb has no demodulator for it (its dump1090 submodule, home of demod_2400.c, is never compiled:
+ * CMakeLists.txt:66-83), so this mode is defined by this library (oracle/oracle2400.c is the specification; parity unpinned):
+ * five sub-sample phases, Manchester decisions by overlap-weighted magnitude differences, the reference's parity / one-bit
+ * repair / AP rules.  Records: `offset` = the sample the frame starts in, `reserved` = the phase (fifths of a sample). */
+#define ADSB_AMD_MODE_2000 20
+#define ADSB_AMD_MODE_2400 24
+int         adsb_amd_create_mode(adsb_amd_ctx_t** out, int device, int mode);
 void        adsb_amd_destroy(adsb_amd_ctx_t* ctx);
 const char* adsb_amd_last_error(const adsb_amd_ctx_t* ctx); /* ctx may be NULL: creation error */
 
@@ -171,6 +180,9 @@ adsb_amd_resolver_t* adsb_amd_resolver_create(void);
 void                 adsb_amd_resolver_destroy(adsb_amd_resolver_t* r);
 /* rate_hz == 0 (default): wall clock, as the reference.  Otherwise time = t0_ns + stream sample index / rate_hz. */
 void adsb_amd_resolver_set_sample_clock(adsb_amd_resolver_t* r, int64_t t0_ns, uint32_t rate_hz);
+/* Samples per microsecond x 10 of the records fed (ADSB_AMD_MODE_*): how many samples an accepted frame hides (ADSB1090.cpp:929-934
+ * skips (8 + bits) * 2; at 2.4 MS/s the same frame spans (8 + bits) * 2.4 samples).  Default 20. */
+void adsb_amd_resolver_set_mode(adsb_amd_resolver_t* r, int mode);
 /*
  * Applies the reference's sequential rules to sorted records of one scan call and fires the
  * callback once per accepted frame, in sample order.  `samples_per_buffer` and `nbuffers` describe
@@ -195,6 +207,7 @@ void adsb_amd_count_callback(void* user, const adsb_amd_frame_t* frame, const ad
 typedef struct adsb_amd_handler adsb_amd_handler_t;
 
 int         adsb_amd_handler_create(adsb_amd_handler_t** out, int device);
+int         adsb_amd_handler_create_mode(adsb_amd_handler_t** out, int device, int mode); /* ADSB_AMD_MODE_*; see adsb_amd_create_mode */
 void        adsb_amd_handler_destroy(adsb_amd_handler_t* h);
 const char* adsb_amd_handler_last_error(const adsb_amd_handler_t* h);
 void        adsb_amd_handler_set_sample_clock(adsb_amd_handler_t* h, int64_t t0_ns, uint32_t rate_hz);

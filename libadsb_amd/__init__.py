@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADSB_AMD_LIB") or os.path.join(_HERE, "libadsb_amd.so")  # override: A/B of build variants only
 
 REF_BUFFER_BYTES = 262144
+MODE_2000, MODE_2400 = 20, 24  # samples per microsecond x 10: the reference's demodulator / the library's own 2.4 MS/s mode
 F_PASS2, F_PHASE, F_NEEDS_ICAO = 1, 2, 4
 
 RECORD_DTYPE = np.dtype([("buffer", "<u4"), ("offset", "<u4"), ("addr", "<u4"), ("reserved", "<u2"), ("nbits", "u1"),
@@ -28,7 +29,7 @@ assert RECORD_DTYPE.itemsize == 32 and FRAME_DTYPE.itemsize == 32 and AIRCRAFT_D
 ON_CHANGED = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
 
 EXPORTS = [
-    "adsb_amd_version", "adsb_amd_create", "adsb_amd_destroy", "adsb_amd_last_error", "adsb_amd_scan_1090",
+    "adsb_amd_version", "adsb_amd_create", "adsb_amd_create_mode", "adsb_amd_handler_create_mode", "adsb_amd_resolver_set_mode", "adsb_amd_destroy", "adsb_amd_last_error", "adsb_amd_scan_1090",
     "adsb_amd_scan_1090_submit", "adsb_amd_scan_1090_fetch", "adsb_amd_scan_1090_fetch_decoded", "adsb_amd_scan_1090_fetch_device", "adsb_amd_scan_1090_timing", "adsb_amd_magnitude_1090",
     "adsb_amd_decode_1090", "adsb_amd_decode_record_host", "adsb_amd_resolver_feed_decoded", "adsb_amd_cpr_nl", "adsb_amd_cpr_global",
     "adsb_amd_resolver_create", "adsb_amd_resolver_destroy", "adsb_amd_resolver_set_sample_clock", "adsb_amd_resolver_feed",
@@ -64,6 +65,9 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.adsb_amd_version.restype = C.c_char_p
         L.adsb_amd_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.adsb_amd_create_mode.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
+        L.adsb_amd_handler_create_mode.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
+        L.adsb_amd_resolver_set_mode.argtypes = [C.c_void_p, C.c_int]
         L.adsb_amd_destroy.argtypes = [C.c_void_p]
         L.adsb_amd_last_error.argtypes = [C.c_void_p]
         L.adsb_amd_last_error.restype = C.c_char_p
@@ -150,10 +154,10 @@ class _Collector:
 class Scanner:
     """GPU half: u8 IQ -> sorted candidate records (adsb_amd_ctx_t)."""
 
-    def __init__(self, device=-1):
+    def __init__(self, device=-1, mode=MODE_2000):
         self._l = lib()
         h = C.c_void_p()
-        rc = self._l.adsb_amd_create(C.byref(h), device)
+        rc = self._l.adsb_amd_create_mode(C.byref(h), device, mode)
         if rc != 0:
             raise AdsbAmdError("adsb_amd_create failed (%d): %s" % (rc, self._l.adsb_amd_last_error(None).decode()))
         self._h = h
@@ -234,10 +238,11 @@ class Scanner:
 class Resolver:
     """Host half: records -> accepted frames + aircraft snapshots (adsb_amd_resolver_t).  Needs no GPU."""
 
-    def __init__(self, sample_clock_hz=2000000, t0_ns=1_600_000_000 * 10**9):
+    def __init__(self, sample_clock_hz=2000000, t0_ns=1_600_000_000 * 10**9, mode=MODE_2000):
         self._l = lib()
         self._h = C.c_void_p(self._l.adsb_amd_resolver_create())
         self._l.adsb_amd_resolver_set_sample_clock(self._h, t0_ns, sample_clock_hz)
+        self._l.adsb_amd_resolver_set_mode(self._h, mode)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -277,10 +282,10 @@ class Resolver:
 class Handler1090:
     """The reference's ADSB1090Handler surface (RTLSDR::IDataHandler::HandleData) over the GPU path."""
 
-    def __init__(self, device=-1, sample_clock_hz=2000000, t0_ns=1_600_000_000 * 10**9):
+    def __init__(self, device=-1, sample_clock_hz=2000000, t0_ns=1_600_000_000 * 10**9, mode=MODE_2000):
         self._l = lib()
         h = C.c_void_p()
-        rc = self._l.adsb_amd_handler_create(C.byref(h), device)
+        rc = self._l.adsb_amd_handler_create_mode(C.byref(h), device, mode)
         if rc != 0:
             raise AdsbAmdError("adsb_amd_handler_create failed (%d): %s" % (rc, self._l.adsb_amd_last_error(None).decode()))
         self._h = h

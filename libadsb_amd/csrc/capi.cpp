@@ -63,6 +63,7 @@ struct Slot
 struct adsb_amd_ctx
 {
     int         device = 0;
+    int         mode   = ADSB_AMD_MODE_2000;
     uint32_t    nxcd = 8, ncu = 256; // topology of the device, read once at create
     hipStream_t stream = nullptr, copy_stream = nullptr;
     uint32_t*   crc_tab = nullptr;
@@ -153,7 +154,7 @@ int make_args(adsb_amd_ctx* c, const void* iq_device, size_t nbytes, size_t buff
     a->buf_stride     = bb;
     a->buf_samples    = (uint32_t)(bb / 2);
     a->nbuf           = (uint32_t)nbuf;
-    a->chunks_per_buf = chunks_per_buffer(a->buf_samples);
+    a->chunks_per_buf = c->mode == ADSB_AMD_MODE_2400 ? chunks_per_buffer_2400(a->buf_samples) : chunks_per_buffer(a->buf_samples);
     uint64_t total    = (uint64_t)a->chunks_per_buf * nbuf;
     if (total > 0x7FFFFFFFull) return fail(c, ADSB_AMD_EINVAL, "input too large for one scan call");
     a->total_chunks = (uint32_t)total;
@@ -175,7 +176,8 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     // kernels do not get onto the chip while 4096 persistent workgroups are being placed.)
     HIP_TRY(c, hipEventRecord(s.ev_begin, s.stream));
     HIP_TRY(c, hipEventRecord(s.ev_scan0, s.stream));
-    HIP_TRY(c, launch_scan1090(s.args, s.total_d, s.stream));
+    if (c->mode == ADSB_AMD_MODE_2400) HIP_TRY(c, launch_scan2400(s.args, s.total_d, s.stream));
+    else HIP_TRY(c, launch_scan1090(s.args, s.total_d, s.stream));
     HIP_TRY(c, hipEventRecord(s.ev_scan1, s.stream));
     HIP_TRY(c, launch_order1090(s.args, s.dense, s.decoded, s.block_sums, s.total_d, s.stream));
     HIP_TRY(c, hipMemcpyAsync(s.total_h, s.total_d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
@@ -186,9 +188,17 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
 
 extern "C" const char* adsb_amd_version(void) { return "libadsb_amd 0.1 (gfx950)"; }
 
-extern "C" int adsb_amd_create(adsb_amd_ctx_t** out, int device)
+extern "C" int adsb_amd_create(adsb_amd_ctx_t** out, int device) { return adsb_amd_create_mode(out, device, ADSB_AMD_MODE_2000); }
+
+extern "C" int adsb_amd_create_mode(adsb_amd_ctx_t** out, int device, int mode)
 {
     if (!out) return ADSB_AMD_EINVAL;
+    if (mode != ADSB_AMD_MODE_2000 && mode != ADSB_AMD_MODE_2400)
+    {
+        *out           = nullptr;
+        g_create_error = "mode must be ADSB_AMD_MODE_2000 or ADSB_AMD_MODE_2400";
+        return ADSB_AMD_EINVAL;
+    }
     *out      = nullptr;
     int ndev  = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -210,6 +220,7 @@ extern "C" int adsb_amd_create(adsb_amd_ctx_t** out, int device)
     adsb_amd_ctx* c = new (std::nothrow) adsb_amd_ctx();
     if (!c) return ADSB_AMD_EHIP;
     c->device = device;
+    c->mode   = mode;
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
         adsb_amd_destroy(c);
@@ -489,13 +500,16 @@ struct adsb_amd_handler
     std::string                    error;
 };
 
-extern "C" int adsb_amd_handler_create(adsb_amd_handler_t** out, int device)
+extern "C" int adsb_amd_handler_create(adsb_amd_handler_t** out, int device) { return adsb_amd_handler_create_mode(out, device, ADSB_AMD_MODE_2000); }
+
+extern "C" int adsb_amd_handler_create_mode(adsb_amd_handler_t** out, int device, int mode)
 {
     if (!out) return ADSB_AMD_EINVAL;
     *out                = nullptr;
     adsb_amd_handler* h = new (std::nothrow) adsb_amd_handler();
     if (!h) return ADSB_AMD_EHIP;
-    int rc = adsb_amd_create(&h->ctx, device);
+    h->resolver.set_mode(mode);
+    int rc = adsb_amd_create_mode(&h->ctx, device, mode);
     if (rc)
     {
         delete h;
@@ -719,6 +733,10 @@ extern "C" void                 adsb_amd_resolver_destroy(adsb_amd_resolver_t* r
 extern "C" void adsb_amd_resolver_set_sample_clock(adsb_amd_resolver_t* r, int64_t t0_ns, uint32_t rate_hz)
 {
     if (r) r->impl.set_sample_clock(t0_ns, rate_hz);
+}
+extern "C" void adsb_amd_resolver_set_mode(adsb_amd_resolver_t* r, int mode)
+{
+    if (r) r->impl.set_mode(mode);
 }
 extern "C" long adsb_amd_resolver_feed(adsb_amd_resolver_t* r, const adsb_amd_record_t* records, size_t n, size_t samples_per_buffer,
                                        size_t nbuffers, adsb_amd_on_changed_fn cb, void* user)

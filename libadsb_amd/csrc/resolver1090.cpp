@@ -222,7 +222,8 @@ long Resolver1090::feed(const adsb_amd_record_t* rec, const adsb_amd_decoded_t* 
         if (dec) apply(dec[i], t, a);
         else apply(decode_record(r.msg, r.df), t, a);
         accepted++;
-        next_offset = static_cast<uint64_t>(r.offset) + static_cast<uint64_t>(8 + r.nbits) * 2 + 1; // :931 then the loop's j++
+        // :931 then the loop's j++.  At 2.4 MS/s the frame's (8 + bits) microseconds are (8 + bits) * 2.4 samples, rounded up.
+        next_offset = static_cast<uint64_t>(r.offset) + (static_cast<uint64_t>(8 + r.nbits) * per_us_x10_ + 9) / 10 + 1;
         if (cb)
         {
             adsb_amd_frame_t fr{};

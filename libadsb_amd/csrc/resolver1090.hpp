@@ -28,6 +28,7 @@ class Resolver1090
   public:
     // rate_hz == 0: wall clock like the reference; otherwise the stream time of the sample.
     void   set_sample_clock(int64_t t0_ns, uint32_t rate_hz);
+    void   set_mode(int samples_per_us_x10) { per_us_x10_ = samples_per_us_x10 == 24 ? 24 : 20; }
     // `dec` (parallel to `rec`): the GPU's decoded fields (adsb_amd_scan_1090_fetch_decoded); NULL: decode on the host (decode1090.h).
     long   feed(const adsb_amd_record_t* rec, const adsb_amd_decoded_t* dec, size_t n, size_t samples_per_buffer, size_t nbuffers,
                 adsb_amd_on_changed_fn cb, void* user);
@@ -118,6 +119,7 @@ class Resolver1090
     uint64_t  ns_per_sample_ = 0; // 10^9 / rate when that is a whole number (2 MS/s: 500), else 0
     uint64_t  rate_recip_  = 0;   // floor(2^64 / rate): quotient estimate for the exact division by the rate
     uint64_t  stream_base_ = 0;
+    uint32_t  per_us_x10_  = 20; // samples per microsecond x 10 of the records (skip-ahead length)
 };
 
 } // namespace adsb_amd

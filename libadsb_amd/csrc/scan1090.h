@@ -76,6 +76,10 @@ hipError_t launch_magnitude1090(const uint8_t* iq, uint16_t* mag, size_t nsample
 // UAT978 phase LUT map (UAT978.cpp:52): phi[k] = lut[I | Q<<8]
 hipError_t launch_phase978(const uint8_t* iq, uint16_t* phi, size_t nsamples, const uint16_t* lut65536, hipStream_t stream);
 
+// ---- the 2.4 MS/s mode (scan2400.hip; definition: oracle/oracle2400.c).  Same ScanArgs, same raw records, same ordering pass.
+uint32_t   chunks_per_buffer_2400(uint32_t buf_samples);
+hipError_t launch_scan2400(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream);
+
 // host-side table builders (exact integer / polynomial arithmetic, no reference text)
 void build_crc_table(uint32_t* tab /* 112 */);
 

@@ -1,0 +1,256 @@
+// scan_common.hip.h -- device helpers shared by the gfx950 scan kernels (scan1090.hip: the reference's 2 samples per microsecond;
+// scan2400.hip: the 2.4 MS/s mode): packed 16-bit arithmetic, u8 IQ -> s = (I-127)^2 + (Q-127)^2, the exact reference magnitude,
+// wave64 reductions on DPP, per-lane parity tables, and the raw record a demodulating wave emits.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+
+#include "scan1090.h"
+
+namespace adsb_amd
+{
+namespace
+{
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short          i16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u16x2    as_pk(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_max(as_pk(a), as_pk(b))); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u32(as_pk(a) - as_pk(b)); }
+
+// Two IQ samples (4 bytes I0 Q0 I1 Q1) -> (s0 | s1 << 16), s = (I-127)^2 + (Q-127)^2 saturated to 32767.
+// 32768 (I = Q = 255) is the only value above 32767 and 32767 itself is not a sum of two squares, so the
+// saturation keeps the order of all reachable values and makes every difference fit in an int16.
+// Six VALU ops per pair of samples: two byte permutes unpack I and Q into 16-bit halves, two packed subtracts remove the
+// 127 offset, one packed multiply and one saturating packed multiply-add (signed clamp = 32767) finish.
+__device__ __forceinline__ uint32_t iq2_to_s2(uint32_t x)
+{
+    const uint32_t i16 = __builtin_amdgcn_perm(0u, x, 0x0C020C00u); // (I0, I1): bytes 0 and 2, zero-extended (selector 0x0C = 0x00)
+    const uint32_t q16 = __builtin_amdgcn_perm(0u, x, 0x0C030C01u); // (Q0, Q1): bytes 1 and 3
+    const u16x2    c   = {127, 127};
+    const uint32_t di  = as_u32(as_pk(i16) - c), dq = as_u32(as_pk(q16) - c);
+    const uint32_t a   = as_u32(as_pk(di) * as_pk(di)); // (I-127)^2 <= 16384, exact modulo 2^16
+    uint32_t       r;
+    asm("v_pk_mad_i16 %0, %1, %1, %2 clamp" : "=v"(r) : "v"(dq), "v"(a));
+    return r;
+}
+
+// (127 - I) and (127 - Q) of two samples as sign-extended 16-bit pairs -> (s_a | s_b << 16), s saturated to 32767 as in iq2_to_s2
+__device__ __forceinline__ uint32_t pair_to_s2(uint32_t di, uint32_t dq)
+{
+    const uint32_t a = as_u32(as_pk(di) * as_pk(di)); // (127-I)^2 <= 16384, exact modulo 2^16
+    uint32_t       r;
+    asm("v_pk_mad_i16 %0, %1, %1, %2 clamp" : "=v"(r) : "v"(dq), "v"(a));
+    return r;
+}
+
+// The same 4 bytes (two samples) of two rows, x from the lower half of the chunk and y from the upper -> two dwords of the image:
+// t0 = (s(x sample 0), s(y sample 0)), t1 = (s(x sample 1), s(y sample 1)).
+// Byte ^ 0x7F is 127 - byte as a signed 8-bit number, for every byte value (127 - 255 = -128 included), so one XOR removes the
+// offset of all four bytes of a register and squaring does not care about the sign.  v_perm_b32 then builds the 16-bit pairs:
+// selector 0..3 = bytes of the second operand, 4..7 = bytes of the first, and 8 / 9 / 10 / 11 replicate the sign bit of byte
+// 1 / 3 / 5 / 7, i.e. it sign-extends the odd bytes (Q) directly; for the even bytes (I) the registers are first shifted up
+// by one byte.  Per dword of the image: 4 half-rate operations (two permutes, multiply, multiply-add) and 2 full-rate ones
+// (the XOR and the shift are shared by the two dwords a register pair yields), where unpack + subtract + square took 6
+// half-rate ones.
+__device__ __forceinline__ void rows_to_s2(uint32_t x, uint32_t y, uint32_t& t0, uint32_t& t1)
+{
+    const uint32_t zx = x ^ 0x7F7F7F7Fu, zy = y ^ 0x7F7F7F7Fu;
+    const uint32_t ux = zx << 8, uy = zy << 8;
+    t0 = pair_to_s2(__builtin_amdgcn_perm(uy, ux, 0x0A050801u), __builtin_amdgcn_perm(zy, zx, 0x0A050801u));
+    t1 = pair_to_s2(__builtin_amdgcn_perm(uy, ux, 0x0B070903u), __builtin_amdgcn_perm(zy, zx, 0x0B070903u));
+}
+
+__device__ __forceinline__ uint32_t iq1_to_s(uint32_t i, uint32_t q)
+{
+    int      di = (int)i - 127, dq = (int)q - 127;
+    uint32_t s  = (uint32_t)(di * di + dq * dq);
+    return s > 32767u ? 32767u : s;
+}
+
+// Exact reference magnitude round(sqrt(s) * 360) (ADSB1090.cpp:138) from the saturated s.
+__device__ __forceinline__ int mag_of_s(uint32_t s)
+{
+    const float    f = __builtin_amdgcn_sqrtf((float)s);
+    const int      m = (int)(uint32_t)__builtin_fmaf(f, 360.0f, 0.5f);
+    const uint32_t t = __umul24(s, 129600u);                  // < 2^32
+    const int      d = (int)(t - (uint32_t)__umul24(m, m));   // m <= 65167: exact in 32 bits
+    // 129600 s > m^2 + m: estimate one too small;  129600 s <= m^2 - m: one too large (max() keeps s = 0 at 0)
+    const int      r = __builtin_elementwise_max(m + (d > m ? 1 : 0) - (d + m <= 0 ? 1 : 0), 0);
+    return (s == 32767u) ? 65167 : r;                          // 32767 stands for s = 32768 (I = Q = 255)
+}
+
+// Float estimate of the same magnitude: |est - 360*sqrt(s)| < 0.05 (v_sqrt_f32 is good to 1 ulp, one more rounding in
+// the multiply; 32767 standing for 32768 costs at most 1.0), hence |est - mag_of_s| < 1.6.
+__device__ __forceinline__ float mag_estimate(uint32_t s) { return __builtin_amdgcn_sqrtf((float)s) * 360.0f; }
+constexpr float kEstErr = 1.6f;
+
+__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+// Ordering point between LDS writes and reads of other lanes of the same wavefront (single-wave workgroups): the
+// hardware executes one wave's LDS instructions in order, the fence only stops the compiler from reordering them.
+// Unlike __syncthreads() it does not wait for outstanding global loads, so the prefetched window stays in flight.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave64 scans / reductions on DPP (no LDS round trips): row_shr 1,2,4,8 inside each row of 16, then
+// row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3.  Lane 63 ends up with the full result.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t x)
+{
+    x += dpp_or_zero<0x111, 0xF>(x);
+    x += dpp_or_zero<0x112, 0xF>(x);
+    x += dpp_or_zero<0x114, 0xF>(x);
+    x += dpp_or_zero<0x118, 0xF>(x);
+    x += dpp_or_zero<0x142, 0xA>(x);
+    x += dpp_or_zero<0x143, 0xC>(x);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add(v), 63); }
+__device__ __forceinline__ uint32_t wave_xor(uint32_t x)
+{
+    x ^= dpp_or_zero<0x111, 0xF>(x);
+    x ^= dpp_or_zero<0x112, 0xF>(x);
+    x ^= dpp_or_zero<0x114, 0xF>(x);
+    x ^= dpp_or_zero<0x118, 0xF>(x);
+    x ^= dpp_or_zero<0x142, 0xA>(x);
+    x ^= dpp_or_zero<0x143, 0xC>(x);
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// mask of bits 0..b (b in 0..63)
+__device__ __forceinline__ uint64_t upto(int b) { return (b >= 63) ? ~0ull : ((2ull << b) - 1ull); }
+
+// Value of a run-length "hold" sequence at bit b: the value at the highest decided position <= b,
+// or `carry` when no position <= b is decided.
+__device__ __forceinline__ uint32_t hold_resolve(uint64_t decided, uint64_t value, int b, uint32_t carry)
+{
+    uint64_t m = decided & upto(b);
+    if (m == 0) return carry;
+    int p = 63 - __builtin_clzll(m);
+    return (uint32_t)((value >> p) & 1ull);
+}
+
+// Two-state chain t_k = t_{k-1} ? up_k : dn_k resolved from ballots: `cst` marks positions where up==dn
+// (value in `val`), `inv` marks positions where the state is inverted (up=0, dn=1); elsewhere identity.
+__device__ __forceinline__ uint32_t chain_resolve(uint64_t cst, uint64_t val, uint64_t inv, int b, uint32_t carry)
+{
+    uint64_t m = cst & upto(b);
+    uint32_t start;
+    uint64_t span;
+    if (m == 0)
+    {
+        start = carry;
+        span  = upto(b);
+    }
+    else
+    {
+        int p = 63 - __builtin_clzll(m);
+        start = (uint32_t)((val >> p) & 1ull);
+        span  = upto(b) & ~upto(p);
+    }
+    return start ^ (uint32_t)(__builtin_popcountll(inv & span) & 1);
+}
+
+constexpr uint64_t kMask48 = (1ull << 48) - 1ull;
+constexpr uint64_t kMask56 = (1ull << 56) - 1ull;
+
+// 112 sliced bits from per-lane decisions: bit b keeps the value of the last decided bit <= b (:838).
+// Fast path (every bit decided, the normal case for a real frame): the value ballots are the message.
+__device__ __forceinline__ void slice_resolve(int lane, bool has_b, bool decided_a, bool value_a, bool decided_b, bool value_b, uint64_t* ba,
+                                              uint64_t* bb)
+{
+    const uint64_t decA = ballot(decided_a), valA = ballot(value_a);
+    const uint64_t decB = ballot(has_b && decided_b), valB = ballot(has_b && value_b);
+    if (decA == ~0ull && decB == kMask48)
+    {
+        *ba = valA;
+        *bb = valB;
+        return;
+    }
+    const uint32_t bitA = hold_resolve(decA, valA, lane, 0u);
+    const uint32_t last = hold_resolve(decA, valA, 63, 0u);
+    const uint32_t bitB = hold_resolve(decB, valB, lane, last);
+    *ba = ballot(bitA != 0);
+    *bb = ballot(has_b && bitB != 0);
+}
+
+struct LaneTables
+{
+    uint32_t syn_a; // 112-bit message: syndrome of flipping bit `lane`
+    uint32_t syn_b; // 112-bit message: syndrome of flipping bit 64+lane (lane < 48)
+    uint32_t syn_s; // 56-bit message: syndrome of flipping bit `lane` (lane < 56)
+    uint32_t crc_a; // parity-table entry of bit `lane` (112-bit)
+    uint32_t crc_b; // parity-table entry of bit 64+lane
+    uint32_t crc_s; // parity-table entry of bit `lane` of a 56-bit message
+};
+
+__device__ __forceinline__ LaneTables load_lane_tables(const uint32_t* __restrict__ tab, int lane)
+{
+    LaneTables t;
+    // ModesChecksumTable semantics (ADSB1090.cpp:266-275): entry b < 88 = x^(111-b) mod G, last 24 entries 0.
+    uint32_t ta = tab[lane];
+    uint32_t tb = (lane < 48) ? tab[64 + lane] : 0u;
+    uint32_t ts = (lane < 56) ? tab[56 + lane] : 0u;
+    t.crc_a     = ta;
+    t.crc_b     = tb;
+    t.crc_s     = ts;
+    // flipping a bit of the parity field itself changes the stored value by that bit (FixSingleBitErrors :304-332)
+    int ba = lane, bb = 64 + lane;
+    t.syn_a = ta; // lane < 64 < 88: always a data bit
+    t.syn_b = (lane < 48) ? ((bb < 88) ? tb : (1u << (111 - bb))) : 0xFFFFFFFFu;
+    t.syn_s = (lane < 56) ? ((ba < 32) ? ts : (1u << (55 - ba))) : 0xFFFFFFFFu;
+    return t;
+}
+
+struct Emit
+{
+    uint4*   base; // this chunk's region, one raw record = 2 x uint4
+    uint32_t cap;
+    uint32_t count; // wave-uniform
+};
+
+// A raw record is what the wave has in scalar registers anyway; turning it into the public adsb_amd_record_t (byte
+// order, repair flip, address extraction) is done later by the gather kernel, one record per lane.
+//   lo = { offset, df | nbits<<8 | flags<<16 | (errorbit+1)<<24, AP xor parity, reserved16 },  hi = message bits 0..127 (bit n = bit n)
+__device__ __forceinline__ void emit_raw(Emit& e, int lane, uint32_t offset, uint64_t ba, uint64_t bb, uint32_t df, uint32_t nbits,
+                                         int errorbit, uint32_t flags, uint32_t syn, uint32_t extra16 = 0u)
+{
+    if (e.count < e.cap)
+    {
+        if (lane == 0)
+        {
+            uint4 lo, hi;
+            lo.x = offset;
+            lo.y = df | (nbits << 8) | (flags << 16) | ((uint32_t)(errorbit + 1) << 24);
+            lo.z = syn;
+            lo.w = extra16; // lands in adsb_amd_record_t::reserved (mode 2400: the sub-sample phase)
+            hi.x = (uint32_t)ba;
+            hi.y = (uint32_t)(ba >> 32);
+            hi.z = (uint32_t)bb;
+            hi.w = (uint32_t)(bb >> 32);
+            e.base[2 * e.count]     = lo;
+            e.base[2 * e.count + 1] = hi;
+        }
+    }
+    e.count++; // counts past cap signal overflow to the ordering pass
+}
+
+__device__ __forceinline__ bool df_is_long(uint32_t df) { return df == 16 || df == 17 || df == 19 || df == 20 || df == 21; }
+__device__ __forceinline__ bool df_is_ap(uint32_t df) { return df == 0 || df == 4 || df == 5 || df == 16 || df == 20 || df == 21 || df == 24; }
+
+} // namespace
+} // namespace adsb_amd

@@ -27,7 +27,8 @@ class Synth978Cfg(C.Structure):
 FRAME978_DTYPE = np.dtype([("start", "<u8"), ("kind", "u1"), ("bad_bytes", "u1"), ("len", "<u2"), ("data", "u1", (432,)), ("pad", "u1", (4,))])
 
 FRAME_DTYPE = np.dtype([("start", "<u4"), ("msg", "u1", (14,)), ("nbits", "u1"), ("flipped_bit", "i1"),
-                        ("half_sample", "u1"), ("amplitude", "u1")])
+                        ("half_sample", "u1"), ("amplitude", "u1"), ("pad", "u1", (2,))])  # sizeof(adsb_synth_frame_t) = 24
+assert FRAME_DTYPE.itemsize == 24
 
 
 def build(force=False):
@@ -67,14 +68,14 @@ def default_cfg(**over):
     return c
 
 
-def fill(buf_index, nbytes=BUFFER_BYTES, cfg=None, manifest=False):
+def fill(buf_index, nbytes=BUFFER_BYTES, cfg=None, manifest=False, rate_x10=20):
     cfg = cfg or default_cfg()
     out = np.empty(nbytes, dtype=np.uint8)
     if manifest:
         fr = np.zeros(4096, dtype=FRAME_DTYPE)
-        n = lib().adsb_synth_fill(C.byref(cfg), buf_index, out.ctypes.data, nbytes, fr.ctypes.data, fr.size)
+        n = lib().adsb_synth_fill_rate(C.byref(cfg), buf_index, out.ctypes.data, nbytes, fr.ctypes.data, fr.size, rate_x10)
         return out, fr[:min(n, fr.size)]
-    lib().adsb_synth_fill(C.byref(cfg), buf_index, out.ctypes.data, nbytes, None, 0)
+    lib().adsb_synth_fill_rate(C.byref(cfg), buf_index, out.ctypes.data, nbytes, None, 0, rate_x10)
     return out
 
 

@@ -97,6 +97,12 @@ int      oracle1090_decode_cpr(double even_lat, double even_lon, double odd_lat,
  * probes above; buffers spread over `nthreads` threads.  Returns the total count (may exceed cap), (size_t)-1 on failure. */
 size_t oracle1090_expected_records(const uint8_t* iq, size_t nbytes, size_t buffer_bytes, void* out, size_t cap, int nthreads);
 
+/* oracle2400.c: the executable specification of the 2.4 MS/s scan mode (no counterpart in the reference; parity unpinned).
+ * s = saturated powers, m = magnitudes of one buffer of n samples. */
+int    oracle2400_gate(const uint16_t* s, size_t n, size_t j);
+int    oracle2400_demod_at(const uint16_t* m, size_t n, size_t j, uint32_t buffer, void* record32_out);
+size_t oracle2400_expected_records(const uint8_t* iq, size_t nbytes, size_t buffer_bytes, void* out, size_t cap);
+
 /* UAT978 phase LUT (UAT978.cpp:76-100): 65536 entries indexed by I | Q<<8 */
 void oracle978_phase_lut(uint16_t* lut65536);
 

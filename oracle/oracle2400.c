@@ -1,0 +1,219 @@
+/*
+ * oracle2400.c -- executable specification of the 2.4 MS/s Mode S scan mode (ADSB_AMD_MODE_2400).
+ *
+ * TEST INFRASTRUCTURE ONLY (part of liboracle1090.so; see oracle1090.h).
+ *
+ * PARITY UNPINNED, and not a restatement of anything in the reference tree: libadsb demodulates 2 samples per microsecond only
+ * (ADSB1090.cpp:148, 757-758); the only 2.4 MS/s demodulator in its ecosystem is flightaware dump1090's demod_2400.c, which the
+ * reference globs into a CMake variable and never compiles or links, and whose submodule directory is empty in the snapshot
+ * (SURVEY.md F3/F5).  BASELINE.json nevertheless quotes its metric on "2.4 MS/s u8 IQ", so the product has a second scan mode for that
+ * rate.  This file DEFINES that mode; the GPU kernel (libadsb_amd/csrc/scan2400.hip) must produce exactly the records this
+ * produces, and generator -> decoder round trips (tests/test_mode2400_*.py) show that it recovers what was transmitted.  The
+ * approach is the publicly known one for this rate -- five sub-sample phases, Manchester decisions by overlap-weighted
+ * differences of magnitudes -- worked out from the signal geometry below, in integer arithmetic throughout:
+ *
+ *   time unit: one fifth of a sample.  A half-microsecond slot lasts 6 fifths (1.2 samples), sample t covers fifths [5t, 5t+5).
+ *   A frame that starts `phi` fifths (0..4) into sample j has its slot k at fifths [phi + 6k, phi + 6k + 6) after 5j:
+ *   pulses in slots 0, 2, 7, 9 (the preamble), then bit b in slots 16 + 2b (first half) and 17 + 2b (second half).
+ *
+ *   m[t]      the reference's magnitude of sample t (ADSB1090.cpp:131-142, 165-173), s[t] = (I-127)^2 + (Q-127)^2 saturated to 32767
+ *   gate(j)   cheap, on s: each of the four pulse regions carries more than four times the mean power of the surely quiet samples:
+ *             2 min(s0+s1, s2+s3, s8+s9, s10+s11+s12) > s-1 + s5 + s6 + s7 + s14 + s15 + s16 + s17,   s_a = s[j+a], s[-1] of a buffer = 0,
+ *             every sum saturating at 65535 (the kernel forms them in packed 16-bit arithmetic)
+ *   E(phi,k)  = sum_t overlap(slot k, sample t) * m[j + t]      overlap in fifths, 0..5
+ *   P(phi)    = sum_{k in 0,2,7,9} E - sum_{k in 1,3,4,5,6,8} E;  phi* = the first phi of maximal P; candidate dropped if P <= 0
+ *   A         = (E(phi*,0) + E(phi*,2) + E(phi*,7) + E(phi*,9)) / 24      pulse amplitude (4 slots x 6 fifths)
+ *   c_b       = sum_{t<4} W[p][t] m[j + i0 + t],  5 i0 + p = phi + 96 + 12 b,  W[p] = first-half overlap minus second-half overlap:
+ *               {5,-3,-2,0} {4,-1,-3,0} {3,1,-4,0} {2,3,-5,0} {1,5,-5,-1};   bit b = (c_b > 0);  weak iff 2 |c_b| < A
+ *   message   DF = bits 0..4, length by DF as in the reference (:295-299); rejected when more than nbits/8 bits are weak;
+ *             DF11/17: accepted with zero syndrome, or with a single-bit repair (first bit in ascending order, :304-332) when at most
+ *             two bits are weak; DF0/4/5/16/20/21/24: conditional record carrying AP xor parity (:396-435) when at most four bits are weak
+ *   phases    tried in the order phi*, phi*+1, phi*-1 (inside 0..4); the first accepted slice is the candidate's record
+ *   scan      j = 0 .. N - 293 of each buffer (the longest window is 19.2 + 268.8 + 1 samples; 292 samples after j are read)
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "oracle1090.h"
+
+#define SPAN2400 292 /* samples after j that a candidate may read */
+
+static int overlap5(int lo, int hi, int t)
+{ /* fifths of [lo, hi) inside sample t */
+    int a = lo > 5 * t ? lo : 5 * t, b = hi < 5 * t + 5 ? hi : 5 * t + 5;
+    return b > a ? b - a : 0;
+}
+
+static long slot_energy(const uint16_t* m, int phi, int k)
+{ /* m points at sample j */
+    const int lo = phi + 6 * k, hi = lo + 6;
+    long      e  = 0;
+    for (int t = lo / 5; 5 * t < hi; t++) e += (long)overlap5(lo, hi, t) * m[t];
+    return e;
+}
+
+int oracle2400_gate(const uint16_t* s, size_t n, size_t j)
+{ /* s = saturated powers of the buffer */
+    if (n <= SPAN2400 || j >= n - SPAN2400) return 0;
+#define SV(a) ((uint32_t)s[j + (a)])
+#define SAT(x) ((x) > 65535u ? 65535u : (x))
+    uint32_t A = SAT(SV(0) + SV(1)), B = SAT(SV(2) + SV(3)), C = SAT(SV(8) + SV(9)), D = SAT(SAT(SV(10) + SV(11)) + SV(12));
+    uint32_t q = j ? (uint32_t)s[j - 1] : 0u;
+    q = SAT(q + SV(5)); q = SAT(q + SV(6)); q = SAT(q + SV(7));
+    q = SAT(q + SV(14)); q = SAT(q + SV(15)); q = SAT(q + SV(16)); q = SAT(q + SV(17));
+    uint32_t lo = A < B ? A : B;
+    lo = lo < C ? lo : C;
+    lo = lo < D ? lo : D;
+    return SAT(2u * lo) > q;
+#undef SAT
+#undef SV
+}
+
+typedef struct slice2400
+{
+    uint8_t  msg[14];
+    int      nbits, df, weak, errorbit, accepted, needs_icao;
+    uint32_t addr;
+} slice2400_t;
+
+static void slice_phase(const uint16_t* m /* at j */, int phi, long amp, slice2400_t* o)
+{
+    static const int W[5][4] = {{5, -3, -2, 0}, {4, -1, -3, 0}, {3, 1, -4, 0}, {2, 3, -5, 0}, {1, 5, -5, -1}};
+    uint8_t bits[112];
+    uint8_t weakb[112];
+    memset(o, 0, sizeof(*o));
+    o->errorbit = -1;
+    for (int b = 0; b < 112; b++)
+    {
+        const int T = phi + 96 + 12 * b, i0 = T / 5, p = T % 5;
+        long      c = 0;
+        for (int t = 0; t < 4; t++) c += (long)W[p][t] * m[i0 + t];
+        bits[b]  = c > 0;
+        weakb[b] = 2 * (c < 0 ? -c : c) < amp;
+    }
+    o->df    = (bits[0] << 4) | (bits[1] << 3) | (bits[2] << 2) | (bits[3] << 1) | bits[4];
+    o->nbits = oracle1090_msglen_bits(o->df);
+    for (int b = 0; b < o->nbits; b++)
+    {
+        if (bits[b]) o->msg[b >> 3] |= (uint8_t)(0x80u >> (b & 7));
+        o->weak += weakb[b];
+    }
+    if (o->weak > o->nbits / 8) return;
+    const int      nb     = o->nbits / 8;
+    const uint32_t stored = ((uint32_t)o->msg[nb - 3] << 16) | ((uint32_t)o->msg[nb - 2] << 8) | o->msg[nb - 1];
+    const uint32_t syn    = oracle1090_checksum(o->msg, o->nbits) ^ stored;
+    if (o->df == 11 || o->df == 17)
+    {
+        if (syn != 0)
+        {
+            if (o->weak > 2) return;
+            o->errorbit = oracle1090_fix_single_bit(o->msg, o->nbits);
+            if (o->errorbit < 0) return;
+        }
+        o->addr     = ((uint32_t)o->msg[1] << 16) | ((uint32_t)o->msg[2] << 8) | o->msg[3];
+        o->accepted = 1;
+    }
+    else if (o->df == 0 || o->df == 4 || o->df == 5 || o->df == 16 || o->df == 20 || o->df == 21 || o->df == 24)
+    {
+        if (o->weak > 4) return;
+        o->addr       = syn;
+        o->needs_icao = 1;
+        o->accepted   = 1;
+    }
+}
+
+/* mirrors adsb_amd_record_t (include/adsb_amd.h): 32 bytes, little endian; `reserved` carries the phase in this mode */
+typedef struct record2400
+{
+    uint32_t buffer, offset, addr;
+    uint16_t phase;
+    uint8_t  nbits;
+    int8_t   errorbit;
+    uint8_t  df, flags;
+    uint8_t  msg[14];
+} record2400_t;
+
+/* One candidate: 1 and *r filled when some phase yields an acceptable frame. */
+int oracle2400_demod_at(const uint16_t* m, size_t n, size_t j, uint32_t buffer, void* rec_out)
+{
+    if (n <= SPAN2400 || j >= n - SPAN2400) return 0;
+    const uint16_t* w = m + j;
+    long            best = 0;
+    int             phi_star = -1;
+    for (int phi = 0; phi < 5; phi++)
+    {
+        long p = slot_energy(w, phi, 0) + slot_energy(w, phi, 2) + slot_energy(w, phi, 7) + slot_energy(w, phi, 9) - slot_energy(w, phi, 1) -
+                 slot_energy(w, phi, 3) - slot_energy(w, phi, 4) - slot_energy(w, phi, 5) - slot_energy(w, phi, 6) - slot_energy(w, phi, 8);
+        if (phi_star < 0 || p > best)
+        {
+            best     = p;
+            phi_star = phi;
+        }
+    }
+    if (best <= 0) return 0;
+    const long amp      = (slot_energy(w, phi_star, 0) + slot_energy(w, phi_star, 2) + slot_energy(w, phi_star, 7) + slot_energy(w, phi_star, 9)) / 24;
+    const int  order[3] = {phi_star, phi_star + 1, phi_star - 1};
+    for (int k = 0; k < 3; k++)
+    {
+        const int phi = order[k];
+        if (phi < 0 || phi > 4) continue;
+        slice2400_t s;
+        slice_phase(w, phi, amp, &s);
+        if (!s.accepted) continue;
+        record2400_t* r = (record2400_t*)rec_out;
+        memset(r, 0, sizeof(*r));
+        r->buffer   = buffer;
+        r->offset   = (uint32_t)j;
+        r->addr     = s.addr;
+        r->phase    = (uint16_t)phi;
+        r->nbits    = (uint8_t)s.nbits;
+        r->errorbit = (int8_t)s.errorbit;
+        r->df       = (uint8_t)s.df;
+        r->flags    = (uint8_t)(s.needs_icao ? 4 : 0);
+        memcpy(r->msg, s.msg, (size_t)(s.nbits / 8));
+        return 1;
+    }
+    return 0;
+}
+
+/* The record array of one scan call in mode 2400 (buffers of buffer_bytes, 0 = the whole input is one; partial trailing buffer ignored).
+ * Writes up to cap records, returns the total, (size_t)-1 on allocation failure. */
+size_t oracle2400_expected_records(const uint8_t* iq, size_t nbytes, size_t buffer_bytes, void* out, size_t cap)
+{
+    size_t bb   = buffer_bytes ? buffer_bytes : (nbytes & ~(size_t)1);
+    size_t nbuf = bb ? nbytes / bb : 0;
+    size_t n    = bb / 2, total = 0;
+    if (nbuf == 0 || n <= SPAN2400) return 0;
+    uint16_t* mag = (uint16_t*)malloc(n * sizeof(uint16_t));
+    uint16_t* pw  = (uint16_t*)malloc(n * sizeof(uint16_t));
+    if (!mag || !pw)
+    {
+        free(mag);
+        free(pw);
+        return (size_t)-1;
+    }
+    for (size_t b = 0; b < nbuf; b++)
+    {
+        const uint8_t* p = iq + b * bb;
+        oracle1090_magnitude(p, bb, mag);
+        for (size_t k = 0; k < n; k++)
+        {
+            int      di = (int)p[2 * k] - 127, dq = (int)p[2 * k + 1] - 127;
+            uint32_t s  = (uint32_t)(di * di + dq * dq);
+            pw[k]       = (uint16_t)(s > 32767u ? 32767u : s);
+        }
+        for (size_t j = 0; j + SPAN2400 < n; j++)
+        {
+            if (!oracle2400_gate(pw, n, j)) continue;
+            record2400_t r;
+            if (oracle2400_demod_at(mag, n, j, (uint32_t)b, &r))
+            {
+                if (total < cap) ((record2400_t*)out)[total] = r;
+                total++;
+            }
+        }
+    }
+    free(mag);
+    free(pw);
+    return total;
+}

@@ -41,7 +41,7 @@ CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Frame), C.POINTER(Aircraft))
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("oracle1090.c", "oracle1090.h", "oracle978.c", "oracle978.h", "expected1090.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle1090.c", "oracle1090.h", "oracle978.c", "oracle978.h", "expected1090.c", "oracle2400.c")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle1090.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -75,6 +75,8 @@ def lib():
         L.oracle1090_gate_offsets.restype = C.c_size_t
         L.oracle1090_expected_records.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
         L.oracle1090_expected_records.restype = C.c_size_t
+        L.oracle2400_expected_records.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.oracle2400_expected_records.restype = C.c_size_t
         L.oracle1090_cpr_nl.argtypes = [C.c_double]
         L.oracle1090_decode_cpr.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -185,6 +187,21 @@ def expected_records(iq, buffer_bytes=0, nthreads=None, dtype=None):
         n = lib().oracle1090_expected_records(iq.ctypes.data, iq.size, buffer_bytes, out.ctypes.data, cap, nthreads)
         if n == C.c_size_t(-1).value:
             raise MemoryError("oracle1090_expected_records")
+        if n <= cap:
+            out = out[:n * 32]
+            return out.view(dtype) if dtype is not None else out.reshape(-1, 32)
+        cap = n
+
+
+def expected_records2400(iq, buffer_bytes=0, dtype=None):
+    """The record array of a scan call in the 2.4 MS/s mode (oracle2400.c: the specification of that mode)."""
+    iq = np.ascontiguousarray(iq, dtype=np.uint8)
+    cap = max(4096, iq.size // 1024)
+    while True:
+        out = np.zeros(cap * 32, dtype=np.uint8)
+        n = lib().oracle2400_expected_records(iq.ctypes.data, iq.size, buffer_bytes, out.ctypes.data, cap)
+        if n == C.c_size_t(-1).value:
+            raise MemoryError("oracle2400_expected_records")
         if n <= cap:
             out = out[:n * 32]
             return out.view(dtype) if dtype is not None else out.reshape(-1, 32)

@@ -1,0 +1,92 @@
+"""The 2.4 MS/s scan mode on the GPU: kernel == its specification (oracle/oracle2400.c), record for record; round trips through the
+handler.  Parity unpinned (no reference demodulates this rate)."""
+import numpy as np
+import pytest
+
+import libadsb_amd as A
+from libadsb_amd import synth
+from oracle import oracle_py as O
+
+import helpers as H
+from test_mode2400_cpu import round_trip
+
+pytestmark = pytest.mark.gpu
+BB = A.REF_BUFFER_BYTES
+
+
+@pytest.fixture(scope="module")
+def scanner24(native_libs):
+    s = A.Scanner(mode=A.MODE_2400)
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("over", [dict(), dict(noise_amp=10), dict(noise_amp=25, amp_lo=40), dict(mean_spacing=300, noise_amp=6),
+                                  dict(pct_bitflip=100, pct_df17=50, pct_df11=50), dict(mean_spacing=0, noise_amp=40),
+                                  dict(noise_amp=0, amp_lo=3, amp_hi=12, mean_spacing=600), dict(amp_lo=120, amp_hi=128, noise_amp=2)])
+def test_records_equal_the_specification(scanner24, over):
+    iq, _ = synth.fill_range(11, 6, cfg=synth.default_cfg(**over), rate_x10=24)
+    H.assert_records_equal(scanner24.scan(iq, BB), O.expected_records2400(iq, BB, dtype=A.RECORD_DTYPE))
+    # the reference's 2 samples per microsecond input through this mode, and uniformly random bytes: still the specification's answer
+    iq20, _ = synth.fill_range(11, 2, cfg=synth.default_cfg(**over))
+    H.assert_records_equal(scanner24.scan(iq20, BB), O.expected_records2400(iq20, BB, dtype=A.RECORD_DTYPE))
+
+
+@pytest.mark.parametrize("nbytes", [0, 2, 584, 586, 588, 600, 8192 + 586, 8192 + 600, 3 * 8192 + 590, 262144 - 2, 262144 + 6, 2 * 262144 + 1000])
+def test_ragged_single_buffer(scanner24, nbytes):
+    base, _ = synth.fill_range(7, 3, cfg=synth.default_cfg(mean_spacing=400), rate_x10=24)
+    iq = base[:nbytes]
+    H.assert_records_equal(scanner24.scan(iq, 0), O.expected_records2400(iq, 0, dtype=A.RECORD_DTYPE))
+
+
+def test_random_bytes_and_constants(scanner24):
+    rng = np.random.default_rng(2400)
+    iq = rng.integers(0, 256, size=2 * BB, dtype=np.uint8)
+    H.assert_records_equal(scanner24.scan(iq, BB), O.expected_records2400(iq, BB, dtype=A.RECORD_DTYPE))
+    for v in (0, 127, 255):
+        assert len(scanner24.scan(np.full(BB, v, dtype=np.uint8), BB)) == 0
+
+
+def test_large_input_properties_and_round_trip(scanner24):
+    nbuf = 512
+    cfg = synth.default_cfg()
+    iq, injected = synth.fill_range(0, nbuf, nthreads=16, rate_x10=24)
+    full = scanner24.scan(iq, BB)
+    a, b = scanner24.scan(iq[:nbuf // 2 * BB], BB), scanner24.scan(iq[nbuf // 2 * BB:], BB)
+    b["buffer"] += nbuf // 2
+    H.assert_records_equal(full, np.concatenate([a, b]))  # buffers are independent units
+    key = full["buffer"].astype(np.uint64) * (1 << 33) + full["offset"].astype(np.uint64)
+    assert np.all(np.diff(key.astype(np.int64)) > 0)
+    pick = np.random.default_rng(1).choice(nbuf, 24, replace=False)
+    for k in pick:
+        want = O.expected_records2400(iq[k * BB:(k + 1) * BB], BB, dtype=A.RECORD_DTYPE)
+        got = full[full["buffer"] == k].copy()
+        got["buffer"] = 0
+        H.assert_records_equal(got, want)
+    total = hit = 0
+    for k in pick[:8]:
+        _, fr = synth.fill(int(k), BB, cfg, manifest=True, rate_x10=24)
+        got = full[full["buffer"] == k]
+        t, h, f = round_trip(got, fr, BB // 2)
+        total, hit = total + t, hit + h
+        assert f == 0
+    assert hit >= 0.97 * total > 300
+
+
+def test_handler_round_trip(native_libs):
+    """HandleData in this mode: every transmitted DF17/DF11 frame with good parity reaches the listener once (the resolver hides the
+    duplicate candidates a frame produces at neighbouring samples), AP-type frames once their address has been seen."""
+    cfg = synth.default_cfg(pct_bitflip=0, pct_halfsample=0)
+    h = A.Handler1090(mode=A.MODE_2400, sample_clock_hz=2400000)
+    seen_msgs, sent = [], []
+    for b in range(6):
+        iq, fr = synth.fill(b, BB, cfg, manifest=True, rate_x10=24)
+        frames, _ = h.handle_data(iq)
+        seen_msgs += [bytes(f["msg"][:f["nbits"] // 8]) for f in frames]
+        sent += [bytes(f["msg"][:int(f["nbits"]) // 8]) for f in fr if int(f["start"]) + 300 < BB // 2 and (int(f["msg"][0]) >> 3) in (11, 17)]
+    h.close()
+    from collections import Counter
+    got, want = Counter(seen_msgs), Counter(sent)
+    recovered = sum(min(got[m], c) for m, c in want.items())
+    assert recovered >= 0.97 * len(sent) > 200
+    assert all(got[m] <= want[m] + 0 for m in want), "a frame must not reach the listener twice"
