@@ -350,75 +350,6 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
     classify_and_emit(e, lane, lt, ba, bb, df, nbits, j, ADSB_AMD_F_PASS2 | ADSB_AMD_F_PHASE, &stateless);
 }
 
-struct ChunkGeom
-{
-    const uint8_t* buf;  // reference buffer base
-    uint32_t       bidx; // buffer index
-    uint32_t       g0;   // first position of the chunk inside the buffer
-    uint32_t       npos; // valid positions in the chunk (<= kChunk)
-    uint32_t       n;    // samples in the buffer
-};
-
-__device__ __forceinline__ ChunkGeom chunk_geom(const ScanArgs& a, uint32_t bidx, uint32_t cidx)
-{
-    ChunkGeom g;
-    g.bidx               = bidx;
-    g.n                  = a.buf_samples;
-    g.g0                 = cidx * (uint32_t)kChunk;
-    const uint32_t limit = g.n - (uint32_t)kFrameSpan; // positions j < limit
-    g.npos               = (limit - g.g0 < (uint32_t)kChunk) ? (limit - g.g0) : (uint32_t)kChunk;
-    g.buf                = a.iq + (uint64_t)g.bidx * a.buf_stride;
-    return g;
-}
-
-// 16 bytes of IQ at sample g of the buffer; samples beyond the buffer end read as I = Q = 127 (s = 0) and are never
-// used by a valid position.  Slow path, only the last chunk of a buffer comes here.
-__device__ __noinline__ uint4 load_iq16_tail(const uint8_t* __restrict__ buf, uint32_t g, uint32_t n)
-{
-    uint32_t w[4] = {0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu};
-    for (uint32_t k = 0; k < 8u; k++)
-    {
-        if (g + k < n)
-        {
-            uint32_t v  = (uint32_t)buf[2ull * (g + k)] | ((uint32_t)buf[2ull * (g + k) + 1] << 8);
-            uint32_t sh = 16u * (k & 1u);
-            w[k >> 1]   = (w[k >> 1] & ~(0xFFFFu << sh)) | (v << sh);
-        }
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-struct RawWindow
-{
-    uint4    row[kRows + 1]; // row 8 only on lanes 0..31
-    uint32_t front;          // lane 0: the two bytes of sample g0-1
-};
-
-__device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWindow& r)
-{
-    const uint32_t gl = g.g0 + 8u * (uint32_t)lane;
-    if (g.g0 + (uint32_t)(kChunk + kHalo) <= g.n)
-    { // whole window inside the buffer (wave-uniform): plain coalesced 16-byte loads, 1 KiB per instruction
-        const uint4* p = reinterpret_cast<const uint4*>(g.buf + 2ull * gl);
-#pragma unroll
-        for (int k = 0; k < kRows; k++) r.row[k] = p[k * (kRowSamples / 8)];
-        r.row[kRows] = (lane < 32) ? p[kRows * (kRowSamples / 8)] : make_uint4(0, 0, 0, 0);
-    }
-    else
-    { // last chunk of a buffer: lanes whose 16 bytes lie inside still use the vector load, the rest the guarded path
-#pragma unroll
-        for (int k = 0; k <= kRows; k++)
-        {
-            const uint32_t gk = gl + (uint32_t)(k * kRowSamples);
-            if (gk + 8u <= g.n) r.row[k] = *reinterpret_cast<const uint4*>(g.buf + 2ull * gk);
-            else if (gk < g.n) r.row[k] = load_iq16_tail(g.buf, gk, g.n);
-            else r.row[k] = make_uint4(0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
-        }
-    }
-    r.front = 0x7F7Fu;
-    if (lane == 0 && g.g0 > 0) r.front = *reinterpret_cast<const uint16_t*>(g.buf + 2ull * (g.g0 - 1));
-}
-
 #ifndef ADSB_AMD_MIN_WAVES
 #define ADSB_AMD_MIN_WAVES 4
 #endif
@@ -439,49 +370,20 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
     const LaneTables lt   = load_lane_tables(a.crc_tab, lane);
     if (blockIdx.x == 0 && lane < 2) total_overflow[lane] = 0; // {record total, overflow flag}: filled by the ordering pass that follows in-stream
 
-    // XCD-aware chunk order: workgroups b and b+8 share an XCD (round-robin dispatch), so give every XCD one
-    // contiguous range of chunks and let its workgroups walk that range together -> halo re-reads hit its L2.
-    // Each XCD range is cut into kSubRanges pieces with a work counter each, so that no more than 128 waves share a counter.
-    const uint32_t nxcd  = a.nxcd;
-    const uint32_t xcd   = blockIdx.x % nxcd;
-    const uint32_t wg    = blockIdx.x / nxcd;          // index of this workgroup among those of its XCD
-    const uint32_t sub   = wg % kSubRanges;
-    const uint32_t slot  = wg / kSubRanges;
-    const uint32_t nslot = gridDim.x / (nxcd * kSubRanges); // grid is a multiple of 8 * kSubRanges
-    const uint32_t range = xcd * kSubRanges + sub;
-    const uint32_t per   = (a.total_chunks + nxcd * kSubRanges - 1) / (nxcd * kSubRanges);
-    const uint32_t first = range * per;
-    const uint32_t end   = (first + per < a.total_chunks) ? first + per : a.total_chunks;
-
-    uint32_t chunk = first + slot;
-    if (chunk >= end) return;
-
-    // The waves that share a SIMD run the same periodic program (memory phase, VALU-bound gates, latency-bound
-    // demodulation); started together they stay in lockstep and the phases never overlap.  Offsetting each wave by its
-    // hardware slot (HW_ID.wave_id, bits 3:0) spreads them over the period so one wave's loads and dependency chains
-    // hide under another's arithmetic.  Purely a scheduling hint: results do not depend on it.
-    {
-        const uint32_t wslot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;
-        for (uint32_t k = 0; k < wslot; k++) __builtin_amdgcn_s_sleep(127);
-    }
-    // Work distribution inside a range: the first two chunks of a wave are fixed (slot, slot + nslot), every later one comes
-    // from the range's counter.  Chunks differ in cost (candidates to demodulate), and with a fixed stride the
-    // slowest of 4096 waves sets the kernel time; the counter is read two chunks ahead, so its latency never shows.
-    // (Every counter on its own 128-byte line and at most 128 waves per counter: 131 072 atomics on eight counters that
-    // shared one line took 1.1 ms; on 32 lines they cost nothing measurable.)
+    // XCD-aware chunk order, one work counter per sub-range, waves offset in time: scan_common.hip.h (WorkRange)
+    const WorkRange wr = work_range(a);
+    uint32_t        chunk = wr.first + wr.slot;
+    if (chunk >= wr.end) return;
+    stagger_wave();
+    const uint32_t end = wr.end, nslot = wr.nslot;
     constexpr uint32_t kGrab = 1;
-    auto grab = [&]() -> uint32_t
-    {
-        uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(&a.work_counters[range * 32u], kGrab);
-        return first + 2u * nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-    };
+    auto grab = [&]() -> uint32_t { return grab_chunk(a, wr, lane); };
     uint32_t  next    = chunk + nslot;
     uint32_t  group   = grab(); // first chunk of the group grabbed last; its chunks are handed out one by one
     uint32_t  in_group = 0;
-    ChunkGeom g     = chunk_geom(a, chunk / a.chunks_per_buf, chunk % a.chunks_per_buf);
+    ChunkGeom g     = chunk_geom(a, chunk / a.chunks_per_buf, chunk % a.chunks_per_buf, kFrameSpan);
     RawWindow raw;
-    load_window(g, lane, raw);
+    load_window<kHalo>(g, lane, raw);
 
     for (;;)
     {
@@ -510,8 +412,8 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         const uint32_t  me  = chunk;
         if (next < end)
         {
-            g = chunk_geom(a, next / a.chunks_per_buf, next % a.chunks_per_buf);
-            load_window(g, lane, raw);
+            g = chunk_geom(a, next / a.chunks_per_buf, next % a.chunks_per_buf, kFrameSpan);
+            load_window<kHalo>(g, lane, raw);
         }
         wave_lds_fence();
 

@@ -5,16 +5,19 @@
 // definition is oracle/oracle2400.c (read that header for the signal geometry and every rule), and this kernel has to produce
 // exactly the records that file produces -- parity unpinned, GPU == specification, generator -> decoder round trips.
 //
-// Shape, MI355X-first like the 2 MS/s kernel but not yet tuned (one wave per chunk, no persistent waves, no register prefetch):
+// Shape, the 2 MS/s kernel's: persistent single-wave workgroups walk XCD-local chunk ranges off work counters, the next chunk's
+// window is prefetched into registers while the current one is processed:
 //   * a wave owns 4096 preamble positions of one buffer, loads the 4416 samples they can touch with 16-byte coalesced loads and
 //     parks s = (I-127)^2 + (Q-127)^2 in the same interleaved LDS image (dword q = s[q] | s[q + 2048] << 16), so one packed
 //     operation serves two positions and "sample q + a" is dword q + a for every a;
 //   * the gate runs dense and packed on that image: pair sums of the four pulse regions against the sum of eight quiet samples,
 //     saturating 16-bit adds, survivors to a queue;
-//   * a candidate is demodulated by the whole wave: exact magnitudes of its 292-sample window once into LDS, the preamble
-//     correlation of the five sub-sample phases on five lanes, then per phase tried lane b slices bit b and bit 64 + b from four
-//     magnitudes with the overlap weights of its own sub-sample position, ballots give the message, parity is the DPP XOR
-//     reduction of per-lane table entries, the one-bit repair a ballot over per-lane syndromes (shared with the 2 MS/s kernel).
+//   * a candidate is demodulated by the whole wave: first the preamble correlation of the five sub-sample phases, on registers
+//     (each row of 16 lanes holds the 13 magnitudes once, weighted for its phase, DPP row sums) -- most gate survivors of noise
+//     end there; then the exact magnitudes of the window into LDS (the first 192 samples, the rest only for a long DF) and per
+//     phase tried lane b slices bit b and bit 64 + b from four magnitudes with the overlap weights of its own sub-sample
+//     position, ballots give the message, parity is the DPP XOR reduction of per-lane table entries, the one-bit repair a
+//     ballot over per-lane syndromes (shared with the 2 MS/s kernel).
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
@@ -47,20 +50,12 @@ __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b)
     return r;
 }
 __device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_min(as_pk(a), as_pk(b))); }
-
-// 16 bytes of IQ at sample g of the buffer (g a multiple of 8); samples at or beyond n read as I = Q = 127 (s = 0)
-__device__ __forceinline__ uint4 load_iq16(const uint8_t* __restrict__ buf, uint32_t g, uint32_t n)
+// the same, opaque to the compiler: min(x, 1) per half written in C turns into two compares, two selects and a permute
+__device__ __forceinline__ uint32_t pk_min_asm(uint32_t a, uint32_t b)
 {
-    if (g + 8u <= n) return *reinterpret_cast<const uint4*>(buf + 2ull * g);
-    uint32_t w[4] = {0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu};
-    for (uint32_t k = 0; k < 8u; k++)
-        if (g + k < n)
-        {
-            const uint32_t v  = (uint32_t)buf[2ull * (g + k)] | ((uint32_t)buf[2ull * (g + k) + 1] << 8);
-            const uint32_t sh = 16u * (k & 1u);
-            w[k >> 1]         = (w[k >> 1] & ~(0xFFFFu << sh)) | (v << sh);
-        }
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // overlap, in fifths of a sample, of the half-microsecond slot k of a frame that starts phi fifths into its first sample with
@@ -70,11 +65,11 @@ constexpr int slot_overlap(int phi, int k, int t)
     const int lo = phi + 6 * k, hi = lo + 6, a = lo > 5 * t ? lo : 5 * t, b = hi < 5 * t + 5 ? hi : 5 * t + 5;
     return b > a ? b - a : 0;
 }
-// per phase and sample: weight of the sample in P(phi) (pulse slots 0, 2, 7, 9 minus quiet slots 1, 3, 4, 5, 6, 8) and in the
-// pulse energy alone.  13 samples cover every slot up to 9 for every phase.
+// per phase and sample: weight of the sample in P(phi) (pulse slots 0, 2, 7, 9 minus quiet slots 1, 3, 4, 5, 6, 8).
+// 13 samples cover every slot up to 9 for every phase.
 struct PreambleWeights
 {
-    int8_t p[5][13], e[5][13];
+    int8_t p[5][13];
 };
 constexpr PreambleWeights make_preamble_weights()
 {
@@ -86,38 +81,60 @@ constexpr PreambleWeights make_preamble_weights()
             for (int k : {0, 2, 7, 9}) pulse += slot_overlap(phi, k, t);
             for (int k : {1, 3, 4, 5, 6, 8}) quiet += slot_overlap(phi, k, t);
             w.p[phi][t] = (int8_t)(pulse - quiet);
-            w.e[phi][t] = (int8_t)pulse;
         }
     return w;
 }
 __constant__ PreambleWeights kPreamble = make_preamble_weights();
 
-// One slice of the window at phase phi (wave-uniform): records what oracle2400.c's slice_phase accepts.  Returns true when a
-// record was emitted.
-__device__ __forceinline__ bool slice_and_emit(const uint16_t* mwin, int lane, const LaneTables& lt, Emit& e, uint32_t j, int phi, int amp)
+// Magnitudes of window samples 64 * pass + lane (pass 0..2: every bit of a short frame and bits 0..63 of a long one; 3..4: the rest)
+__device__ __forceinline__ void window_magnitudes(uint16_t* mwin, const uint16_t* img16, uint32_t a0, int lane, int first, int last)
 {
-    // bit b = lane (A) and 64 + lane (B, lanes < 48): 5 i0 + p = phi + 96 + 12 b; weights of phase p: {5-p, 2p-3, -min(2+p,5), -(p==4)}
-    int  c[2];
-    bool has_b = lane < 48;
 #pragma unroll
-    for (int h = 0; h < 2; h++)
+    for (int i = first; i <= last; i++)
     {
-        const int b  = lane + 64 * h;
-        const int T  = phi + 96 + 12 * (h == 0 || has_b ? b : lane);
+        const int tt = lane + 64 * i;
+        if (tt < kWinSamples) mwin[tt] = (uint16_t)mag_of_s(img16[a0 + 2 * tt]);
+    }
+    wave_lds_fence();
+}
+
+// One slice of the window at phase phi (wave-uniform): records what oracle2400.c's slice_phase accepts (the rejections in a
+// cheaper order: the DF before the second half is even looked at).  Returns true when a record was emitted.  have_tail: whether
+// mwin holds samples 192.. of this candidate already.
+__device__ __forceinline__ bool slice_and_emit(uint16_t* mwin, const uint16_t* img16, uint32_t a0, bool& have_tail, int lane, const LaneTables& lt,
+                                               Emit& e, uint32_t j, int phi, int amp)
+{
+    // bit b: 5 i0 + p = phi + 96 + 12 b; weights of phase p: {5-p, 2p-3, -min(2+p,5), -(p==4)}
+    auto corr = [&](int b) {
+        const int T  = phi + 96 + 12 * b;
         const int i0 = T / 5, p = T - 5 * i0;
         const int w2 = (2 + p < 5) ? 2 + p : 5;
-        c[h] = (5 - p) * (int)mwin[i0] + (2 * p - 3) * (int)mwin[i0 + 1] - w2 * (int)mwin[i0 + 2] - (p == 4 ? (int)mwin[i0 + 3] : 0);
-    }
-    const uint64_t valA = ballot(c[0] > 0), valB = ballot(has_b && c[1] > 0);
-    const uint64_t wkA = ballot(2 * abs(c[0]) < amp), wkB = ballot(has_b && 2 * abs(c[1]) < amp);
+        return (5 - p) * (int)mwin[i0] + (2 * p - 3) * (int)mwin[i0 + 1] - w2 * (int)mwin[i0 + 2] - (p == 4 ? (int)mwin[i0 + 3] : 0);
+    };
+    const int      cA      = corr(lane);
+    const uint64_t valA    = ballot(cA > 0);
     const uint32_t df      = (uint32_t)(__builtin_bitreverse64(valA) >> 59);
+    const bool     is17    = (df == 11 || df == 17);
+    if (!is17 && !df_is_ap(df)) return false;
+    const uint64_t wkA     = ballot(2 * abs(cA) < amp);
     const bool     is_long = df_is_long(df);
     const uint32_t nbits   = is_long ? 112u : 56u;
-    const uint64_t ba = is_long ? valA : (valA & kMask56), bb = is_long ? valB : 0ull;
-    const int      weak = is_long ? __builtin_popcountll(wkA) + __builtin_popcountll(wkB) : __builtin_popcountll(wkA & kMask56);
+    const bool     has_b   = lane < 48;
+    uint64_t       ba = valA & kMask56, bb = 0ull;
+    int            weak = __builtin_popcountll(wkA & kMask56);
+    if (is_long)
+    {
+        if (!have_tail)
+        {
+            window_magnitudes(mwin, img16, a0, lane, 3, 4);
+            have_tail = true;
+        }
+        const int cB = corr(has_b ? 64 + lane : lane);
+        ba           = valA;
+        bb           = ballot(has_b && cB > 0);
+        weak         = __builtin_popcountll(wkA) + __builtin_popcountll(ballot(has_b && 2 * abs(cB) < amp));
+    }
     if (weak > (int)nbits / 8) return false;
-    const bool is17 = (df == 11 || df == 17);
-    if (!is17 && !df_is_ap(df)) return false;
     uint32_t contrib, stored;
     if (is_long)
     {
@@ -150,7 +167,17 @@ __device__ __forceinline__ bool slice_and_emit(const uint16_t* mwin, int lane, c
     return true;
 }
 
-__global__ __launch_bounds__(64) void scan2400_kernel(ScanArgs a)
+// inclusive sums inside each row of 16 lanes (lane 15 of the row ends with the row's total)
+__device__ __forceinline__ int row_scan_add(int x)
+{
+    x += (int)dpp_or_zero<0x111, 0xF>((uint32_t)x);
+    x += (int)dpp_or_zero<0x112, 0xF>((uint32_t)x);
+    x += (int)dpp_or_zero<0x114, 0xF>((uint32_t)x);
+    x += (int)dpp_or_zero<0x118, 0xF>((uint32_t)x);
+    return x;
+}
+
+__global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow)
 {
     __shared__ __attribute__((aligned(16))) uint32_t img[kImgDwords];
     __shared__ uint16_t                              mwin[kWinSamples + 8];
@@ -159,38 +186,53 @@ __global__ __launch_bounds__(64) void scan2400_kernel(ScanArgs a)
 
     const int        lane = threadIdx.x;
     const LaneTables lt   = load_lane_tables(a.crc_tab, lane);
-    const uint32_t   me   = blockIdx.x;
-    if (me >= a.total_chunks) return;
-    const uint32_t bidx = me / a.chunks_per_buf, cidx = me % a.chunks_per_buf;
-    const uint8_t* buf  = a.iq + (uint64_t)bidx * a.buf_stride;
-    const uint32_t n    = a.buf_samples;
-    const uint32_t g0   = cidx * (uint32_t)kChunk;
-    const uint32_t lim  = n - (uint32_t)kSpan24; // positions j < lim
-    const uint32_t npos = (lim - g0 < (uint32_t)kChunk) ? (lim - g0) : (uint32_t)kChunk;
+    // preamble weights of this lane (see the candidate loop)
+    const int tl = lane & 15, rw = lane >> 4;
+    const int wp = tl < 13 ? (int)kPreamble.p[rw][tl] : 0;
+    const int wq = rw == 0 ? (tl < 13 ? (int)kPreamble.p[4][tl] : 0) : (rw == 1 && tl >= 1 && tl <= 11 ? 1 : 0);
+    if (blockIdx.x == 0 && lane < 2) total_overflow[lane] = 0; // {record total, overflow flag}: filled by the ordering pass that follows in-stream
 
+    // persistent waves, chunk order and work counters as in scan1090_kernel (scan_common.hip.h)
+    const WorkRange wr    = work_range(a);
+    uint32_t        chunk = wr.first + wr.slot;
+    if (chunk >= wr.end) return;
+    stagger_wave();
+    uint32_t  next  = chunk + wr.nslot;
+    uint32_t  ahead = grab_chunk(a, wr, lane);
+    ChunkGeom g     = chunk_geom(a, chunk / a.chunks_per_buf, chunk % a.chunks_per_buf, kSpan24);
+    RawWindow raw;
+    load_window<kHalo24>(g, lane, raw);
+
+    for (;;)
+    {
     // ---------------- window -> s, the two halves of the chunk interleaved (rows j and j + 4; j = 4: row 4 again beside the halo row)
+    wave_lds_fence(); // readers of the previous chunk are done
 #pragma unroll
     for (int jr = 0; jr <= kRows / 2; jr++)
     {
-        if (jr == kRows / 2 && lane >= kHalo24 / 8) break;
-        const uint4 x = load_iq16(buf, g0 + (uint32_t)(jr * kRowSamples + 8 * lane), n);
-        const uint4 y = load_iq16(buf, g0 + (uint32_t)((jr + kRows / 2) * kRowSamples + 8 * lane), n);
+        const uint4 x = raw.row[jr], y = raw.row[jr + kRows / 2];
         uint32_t    t[8];
         rows_to_s2(x.x, y.x, t[0], t[1]);
         rows_to_s2(x.y, y.y, t[2], t[3]);
         rows_to_s2(x.z, y.z, t[4], t[5]);
         rows_to_s2(x.w, y.w, t[6], t[7]);
-        uint4* dst = reinterpret_cast<uint4*>(&img[kImgBase + jr * kRowSamples + 8 * lane]);
-        dst[0]     = make_uint4(t[0], t[1], t[2], t[3]);
-        dst[1]     = make_uint4(t[4], t[5], t[6], t[7]);
+        if (jr < kRows / 2 || lane < kHalo24 / 8)
+        {
+            uint4* dst = reinterpret_cast<uint4*>(&img[kImgBase + jr * kRowSamples + 8 * lane]);
+            dst[0]     = make_uint4(t[0], t[1], t[2], t[3]);
+            dst[1]     = make_uint4(t[4], t[5], t[6], t[7]);
+        }
         // the dword in front of q = 0: low half = the sample before the chunk (0 at the start of a buffer), high half = s[2047]
         if (jr == kRows / 2 - 1 && lane == 63) img16[2 * (kImgBase - 1) + 1] = (uint16_t)t[7];
     }
-    if (lane == 0)
+    if (lane == 0) img16[2 * (kImgBase - 1)] = (uint16_t)iq1_to_s(raw.front & 0xFFu, raw.front >> 8);
+
+    // ---------------- prefetch: the next chunk's loads fly while this chunk is processed
+    const uint32_t me = chunk, g0 = g.g0, npos = g.npos;
+    if (next < wr.end)
     {
-        uint32_t f = 0;
-        if (g0 > 0) f = iq1_to_s(buf[2ull * (g0 - 1)], buf[2ull * (g0 - 1) + 1]);
-        img16[2 * (kImgBase - 1)] = (uint16_t)f;
+        g = chunk_geom(a, next / a.chunks_per_buf, next % a.chunks_per_buf, kSpan24);
+        load_window<kHalo24>(g, lane, raw);
     }
     wave_lds_fence();
 
@@ -201,7 +243,7 @@ __global__ __launch_bounds__(64) void scan2400_kernel(ScanArgs a)
     {
         // T[i] = dword q0 - 4 + i of the image, q0 = 512 b + 8 lane: sample a of position q0 + k is T[4 + k + a]
         uint32_t        T[32];
-        const uint32_t* p = &img[kImgBase + b * 512 + 8 * lane - 4];
+        const uint32_t* p = static_cast<const uint32_t*>(__builtin_assume_aligned(&img[kImgBase + b * 512 + 8 * lane - 4], 16));
 #pragma unroll
         for (int i = 0; i < 8; i++)
         {
@@ -222,7 +264,7 @@ __global__ __launch_bounds__(64) void scan2400_kernel(ScanArgs a)
             q                 = pk_add_sat(q, P2[z + 14]);
             q                 = pk_add_sat(q, P2[z + 16]);
             const uint32_t lo = pk_min_u(pk_min_u(A, B), pk_min_u(C, D));
-            const uint32_t ok = pk_min_u(pk_sub_sat(pk_add_sat(lo, lo), q), 0x00010001u); // 1 per half where 2 lo > q
+            const uint32_t ok = pk_min_asm(pk_sub_sat(pk_add_sat(lo, lo), q), 0x00010001u); // 1 per half where 2 lo > q
             const u16x2    wt = {(unsigned short)(1u << k), (unsigned short)(256u << k)};
             acc               = __builtin_amdgcn_udot2(as_pk(ok), wt, acc, false);
         }
@@ -242,6 +284,14 @@ __global__ __launch_bounds__(64) void scan2400_kernel(ScanArgs a)
     }
 
     // ---------------- candidates -> queue -> demodulation, kQueue24 per pass
+#if defined(ADSB_AMD_PARTS24) && ADSB_AMD_PARTS24 == 1
+    if (lane == 0) a.chunk_counts[me] = (surv == 0x123456789ull) ? 1 : 0; // keeps the gate alive
+    if (next >= wr.end) break;
+    chunk = next;
+    next  = ahead;
+    if (next < wr.end) ahead = grab_chunk(a, wr, lane);
+    continue;
+#endif
     const uint32_t mine = (uint32_t)__builtin_popcountll(surv);
     const uint32_t incl = wave_incl_scan_add(mine);
     const uint32_t n1   = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -268,49 +318,46 @@ __global__ __launch_bounds__(64) void scan2400_kernel(ScanArgs a)
         {
             const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)queue[t]);
             const uint32_t a0  = 2u * (uint32_t)kImgBase + 2u * (pos & (uint32_t)(kHalfChunk - 1)) + (pos >> 11); // half of sample t = 0
-            // exact magnitudes of the window, once
-            wave_lds_fence();
-#pragma unroll
-            for (int i = 0; i < 5; i++)
+            // preamble correlation first, on registers: lane 16 r + t holds sample t (13 of them matter) for phase r = 0..3 in wp;
+            // wq carries phase 4 in row 0 and the plain sum of samples 1..11 in row 1.  Most gate survivors of noise end here.
+            const int m  = mag_of_s(img16[a0 + 2 * (lane & 15)]);
+            const int vp = row_scan_add(wp * m), vq = row_scan_add(wq * m);
+            int best = __builtin_amdgcn_readlane(vp, 15), phi_star = 0;
             {
-                const int tt = lane + 64 * i;
-                if (tt < kWinSamples) mwin[tt] = (uint16_t)mag_of_s(img16[a0 + 2 * tt]);
-            }
-            wave_lds_fence();
-            // preamble correlation of the five phases, one per lane
-            int P = 0, E = 0;
-            if (lane < 5)
-            {
-#pragma unroll
-                for (int tt = 0; tt < 13; tt++)
-                {
-                    const int m = (int)mwin[tt];
-                    P += (int)kPreamble.p[lane][tt] * m;
-                    E += (int)kPreamble.e[lane][tt] * m;
-                }
-            }
-            int best = __builtin_amdgcn_readlane(P, 0), phi_star = 0;
-#pragma unroll
-            for (int phi = 1; phi < 5; phi++)
-            {
-                const int v = __builtin_amdgcn_readlane(P, phi);
-                if (v > best) best = v, phi_star = phi;
+                const int p1 = __builtin_amdgcn_readlane(vp, 31), p2 = __builtin_amdgcn_readlane(vp, 47), p3 = __builtin_amdgcn_readlane(vp, 63),
+                          p4 = __builtin_amdgcn_readlane(vq, 15);
+                if (p1 > best) best = p1, phi_star = 1;
+                if (p2 > best) best = p2, phi_star = 2;
+                if (p3 > best) best = p3, phi_star = 3;
+                if (p4 > best) best = p4, phi_star = 4;
             }
             if (best <= 0) continue;
-            int amp = 0;
-#pragma unroll
-            for (int phi = 0; phi < 5; phi++)
-            {
-                const int v = __builtin_amdgcn_readlane(E, phi);
-                if (phi == phi_star) amp = v / 24;
-            }
-            if (slice_and_emit(mwin, lane, lt, e, g0 + pos, phi_star, amp)) continue;
-            if (phi_star + 1 <= 4 && slice_and_emit(mwin, lane, lt, e, g0 + pos, phi_star + 1, amp)) continue;
-            if (phi_star - 1 >= 0) (void)slice_and_emit(mwin, lane, lt, e, g0 + pos, phi_star - 1, amp);
+#if defined(ADSB_AMD_PARTS24) && ADSB_AMD_PARTS24 == 2
+            if (best != 0x12345678) continue;
+#endif
+            // pulse energy of the winning phase: pulse - quiet = P and pulse + quiet = the samples' overlap with [phi, phi + 60) fifths,
+            // which is 5 (s1 + .. + s11) + (5 - phi) s0 + phi s12
+            const int total = 5 * __builtin_amdgcn_readlane(vq, 31) + (5 - phi_star) * __builtin_amdgcn_readlane(m, 0) + phi_star * __builtin_amdgcn_readlane(m, 12);
+            const int amp   = ((best + total) >> 1) / 24;
+            wave_lds_fence(); // the previous candidate's readers are done with mwin
+            window_magnitudes(mwin, img16, a0, lane, 0, 2);
+            bool have_tail = false;
+            if (slice_and_emit(mwin, img16, a0, have_tail, lane, lt, e, g0 + pos, phi_star, amp)) continue;
+#if defined(ADSB_AMD_PARTS24) && ADSB_AMD_PARTS24 == 3
+            continue;
+#endif
+            if (phi_star + 1 <= 4 && slice_and_emit(mwin, img16, a0, have_tail, lane, lt, e, g0 + pos, phi_star + 1, amp)) continue;
+            if (phi_star - 1 >= 0) (void)slice_and_emit(mwin, img16, a0, have_tail, lane, lt, e, g0 + pos, phi_star - 1, amp);
         }
         wave_lds_fence();
     }
     if (lane == 0) a.chunk_counts[me] = e.count;
+
+    if (next >= wr.end) break;
+    chunk = next;
+    next  = ahead;
+    if (next < wr.end) ahead = grab_chunk(a, wr, lane);
+    }
 }
 
 } // namespace
@@ -323,9 +370,12 @@ uint32_t chunks_per_buffer_2400(uint32_t buf_samples)
 
 hipError_t launch_scan2400(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream)
 {
-    hipError_t e = hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
-    if (e != hipSuccess || a.total_chunks == 0) return e;
-    hipLaunchKernelGGL(scan2400_kernel, dim3(a.total_chunks), dim3(64), 0, stream, a);
+    if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
+    // persistent single-wave workgroups, as many as the LDS lets a CU hold (15 x 10.6 KB), in whole (XCD, sub-range) units
+    const uint32_t unit = a.nxcd * kSubRanges;
+    uint32_t       grid = (a.ncu * 15u / unit) * unit;
+    if (grid > a.total_chunks) grid = ((a.total_chunks + unit - 1u) / unit) * unit;
+    hipLaunchKernelGGL(scan2400_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
     return hipGetLastError();
 }
 

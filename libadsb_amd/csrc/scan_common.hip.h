@@ -252,5 +252,126 @@ __device__ __forceinline__ void emit_raw(Emit& e, int lane, uint32_t offset, uin
 __device__ __forceinline__ bool df_is_long(uint32_t df) { return df == 16 || df == 17 || df == 19 || df == 20 || df == 21; }
 __device__ __forceinline__ bool df_is_ap(uint32_t df) { return df == 0 || df == 4 || df == 5 || df == 16 || df == 20 || df == 21 || df == 24; }
 
+// ------------------------------------------------------------------------------------------------
+// chunk geometry, the raw window of a chunk in registers, and the work distribution of the persistent scan kernels
+// ------------------------------------------------------------------------------------------------
+struct ChunkGeom
+{
+    const uint8_t* buf;  // reference buffer base
+    uint32_t       bidx; // buffer index
+    uint32_t       g0;   // first position of the chunk inside the buffer
+    uint32_t       npos; // valid positions in the chunk (<= kChunk)
+    uint32_t       n;    // samples in the buffer
+};
+
+// span: samples after a position a candidate there may read (positions j < n - span)
+__device__ __forceinline__ ChunkGeom chunk_geom(const ScanArgs& a, uint32_t bidx, uint32_t cidx, int span)
+{
+    ChunkGeom g;
+    g.bidx               = bidx;
+    g.n                  = a.buf_samples;
+    g.g0                 = cidx * (uint32_t)kChunk;
+    const uint32_t limit = g.n - (uint32_t)span;
+    g.npos               = (limit - g.g0 < (uint32_t)kChunk) ? (limit - g.g0) : (uint32_t)kChunk;
+    g.buf                = a.iq + (uint64_t)g.bidx * a.buf_stride;
+    return g;
+}
+
+// 16 bytes of IQ at sample g of the buffer; samples beyond the buffer end read as I = Q = 127 (s = 0) and are never
+// used by a valid position.  Slow path, only the last chunk of a buffer comes here.
+__device__ __noinline__ uint4 load_iq16_tail(const uint8_t* __restrict__ buf, uint32_t g, uint32_t n)
+{
+    uint32_t w[4] = {0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu};
+    for (uint32_t k = 0; k < 8u; k++)
+    {
+        if (g + k < n)
+        {
+            uint32_t v  = (uint32_t)buf[2ull * (g + k)] | ((uint32_t)buf[2ull * (g + k) + 1] << 8);
+            uint32_t sh = 16u * (k & 1u);
+            w[k >> 1]   = (w[k >> 1] & ~(0xFFFFu << sh)) | (v << sh);
+        }
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+struct RawWindow
+{
+    uint4    row[kRows + 1]; // row 8 (the halo) only on lanes 0 .. HALO / 8 - 1
+    uint32_t front;          // lane 0: the two bytes of sample g0-1
+};
+
+// HALO: samples after the chunk's 4096 that belong to the window (a multiple of 8, at most one row)
+template <int HALO>
+__device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWindow& r)
+{
+    const uint32_t gl = g.g0 + 8u * (uint32_t)lane;
+    if (g.g0 + (uint32_t)(kChunk + HALO) <= g.n)
+    { // whole window inside the buffer (wave-uniform): plain coalesced 16-byte loads, 1 KiB per instruction
+        const uint4* p = reinterpret_cast<const uint4*>(g.buf + 2ull * gl);
+#pragma unroll
+        for (int k = 0; k < kRows; k++) r.row[k] = p[k * (kRowSamples / 8)];
+        r.row[kRows] = (lane < HALO / 8) ? p[kRows * (kRowSamples / 8)] : make_uint4(0, 0, 0, 0);
+    }
+    else
+    { // last chunk of a buffer: lanes whose 16 bytes lie inside still use the vector load, the rest the guarded path
+#pragma unroll
+        for (int k = 0; k <= kRows; k++)
+        {
+            const uint32_t gk = gl + (uint32_t)(k * kRowSamples);
+            if (gk + 8u <= g.n) r.row[k] = *reinterpret_cast<const uint4*>(g.buf + 2ull * gk);
+            else if (gk < g.n) r.row[k] = load_iq16_tail(g.buf, gk, g.n);
+            else r.row[k] = make_uint4(0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
+        }
+    }
+    r.front = 0x7F7Fu;
+    if (lane == 0 && g.g0 > 0) r.front = *reinterpret_cast<const uint16_t*>(g.buf + 2ull * (g.g0 - 1));
+}
+
+// XCD-aware chunk order: workgroups b and b + nxcd share an XCD (round-robin dispatch), so give every XCD one contiguous range
+// of chunks and let its workgroups walk that range together -> halo re-reads hit its L2.  Each XCD range is cut into kSubRanges
+// pieces with a work counter each, so that no more than 128 waves share a counter.
+struct WorkRange
+{
+    uint32_t first, end; // chunks of this wave's sub-range
+    uint32_t slot;       // index of the wave among those of the sub-range
+    uint32_t nslot;      // waves per sub-range
+    uint32_t range;      // which counter
+};
+__device__ __forceinline__ WorkRange work_range(const ScanArgs& a)
+{
+    WorkRange      w;
+    const uint32_t nxcd = a.nxcd;
+    const uint32_t xcd  = blockIdx.x % nxcd;
+    const uint32_t wg   = blockIdx.x / nxcd; // index of this workgroup among those of its XCD
+    const uint32_t sub  = wg % kSubRanges;
+    w.slot              = wg / kSubRanges;
+    w.nslot             = gridDim.x / (nxcd * kSubRanges); // the grid is a multiple of nxcd * kSubRanges
+    w.range             = xcd * kSubRanges + sub;
+    const uint32_t per  = (a.total_chunks + nxcd * kSubRanges - 1) / (nxcd * kSubRanges);
+    w.first             = w.range * per;
+    w.end               = (w.first + per < a.total_chunks) ? w.first + per : a.total_chunks;
+    return w;
+}
+// The waves that share a SIMD run the same periodic program (memory phase, VALU-bound gates, latency-bound demodulation);
+// started together they stay in lockstep and the phases never overlap.  Offsetting each wave by its hardware slot
+// (HW_ID.wave_id, bits 3:0) spreads them over the period so one wave's loads and dependency chains hide under another's
+// arithmetic.  Purely a scheduling hint: results do not depend on it.
+__device__ __forceinline__ void stagger_wave()
+{
+    const uint32_t wslot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;
+    for (uint32_t k = 0; k < wslot; k++) __builtin_amdgcn_s_sleep(127);
+}
+// Work distribution inside a range: the first two chunks of a wave are fixed (slot, slot + nslot), every later one comes from
+// the range's counter.  Chunks differ in cost (candidates to demodulate), and with a fixed stride the slowest of 4096 waves
+// sets the kernel time; the counter is read two chunks ahead, so its latency never shows.  (Every counter on its own 128-byte
+// line and at most 128 waves per counter: 131 072 atomics on eight counters that shared one line took 1.1 ms; on 32 lines they
+// cost nothing measurable.)
+__device__ __forceinline__ uint32_t grab_chunk(const ScanArgs& a, const WorkRange& w, int lane)
+{
+    uint32_t v = 0;
+    if (lane == 0) v = atomicAdd(&a.work_counters[w.range * 32u], 1u);
+    return w.first + 2u * w.nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 } // namespace
 } // namespace adsb_amd

@@ -217,3 +217,28 @@ size_t oracle2400_expected_records(const uint8_t* iq, size_t nbytes, size_t buff
     free(pw);
     return total;
 }
+
+/* diagnostics for tuning (not used by the tests): gate passes, and for each the best preamble score and pulse energy */
+size_t oracle2400_gate_stats(const uint8_t* iq, size_t nbytes, long* out_p, long* out_e, uint32_t* out_j, size_t cap)
+{
+    size_t n = nbytes / 2, k = 0;
+    uint16_t* mag = (uint16_t*)malloc(n * 2); uint16_t* pw = (uint16_t*)malloc(n * 2);
+    oracle1090_magnitude(iq, nbytes, mag);
+    for (size_t i = 0; i < n; i++) { int di = (int)iq[2*i]-127, dq = (int)iq[2*i+1]-127; uint32_t s = (uint32_t)(di*di+dq*dq); pw[i] = (uint16_t)(s > 32767u ? 32767u : s); }
+    for (size_t j = 0; j + SPAN2400 < n; j++)
+    {
+        if (!oracle2400_gate(pw, n, j)) continue;
+        long best = 0, e = 0; int ps = -1;
+        for (int phi = 0; phi < 5; phi++)
+        {
+            const uint16_t* w = mag + j;
+            long pe = slot_energy(w, phi, 0) + slot_energy(w, phi, 2) + slot_energy(w, phi, 7) + slot_energy(w, phi, 9);
+            long p = pe - slot_energy(w, phi, 1) - slot_energy(w, phi, 3) - slot_energy(w, phi, 4) - slot_energy(w, phi, 5) - slot_energy(w, phi, 6) - slot_energy(w, phi, 8);
+            if (ps < 0 || p > best) { best = p; ps = phi; e = pe; }
+        }
+        if (k < cap) { out_p[k] = best; out_e[k] = e; out_j[k] = (uint32_t)j; }
+        k++;
+    }
+    free(mag); free(pw);
+    return k;
+}

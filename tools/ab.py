@@ -1,6 +1,7 @@
 """In-process A/B of kernel variants selected by environment knobs (read per submit): interleaved rounds, median kernel ms.
 
     python tools/ab.py "lib=ab_libs/a.so" "lib=ab_libs/b.so" ...
+    AB_RATE=24 python tools/ab.py ...      the 2.4 MS/s mode and its workload
 """
 import os
 import sys
@@ -16,7 +17,9 @@ variants = [dict(kv.split("=") for kv in v.split(",") if kv) for v in sys.argv[1
 # a variant may name its own build of the library: lib=ab_libs/foo.so (see tools/build_variant.sh)
 BB = A.REF_BUFFER_BYTES
 nbuf = 4096
-iq, _ = synth.fill_range(0, nbuf, nthreads=16)
+RATE = int(os.environ.get("AB_RATE", "20"))
+MODE = A.MODE_2400 if RATE == 24 else A.MODE_2000
+iq, _ = synth.fill_range(0, nbuf, nthreads=16, rate_x10=RATE)
 d = torch.from_numpy(iq).cuda()
 torch.cuda.synchronize()
 import ctypes as C
@@ -27,7 +30,7 @@ def scanner_for(v):
         if path:
             A._lib = None
             A.LIB_PATH = os.path.abspath(path)
-        scanners[path] = A.Scanner(0)
+        scanners[path] = A.Scanner(0, mode=MODE)
     return scanners[path]
 st = torch.cuda.current_stream().cuda_stream
 keys = sorted({k for v in variants for k in v})
