@@ -238,18 +238,25 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
 
     // ---------------- gate (oracle2400_gate), packed: 2 min(s0+s1, s2+s3, s8+s9, s10+s11+s12) > s-1 + s5+s6+s7 + s14+s15+s16+s17
     uint32_t surv32[2] = {0u, 0u};
-#pragma unroll 1
+#pragma unroll
     for (int b = 0; b < kHalfChunk / 512; b++)
     {
         // T[i] = dword q0 - 4 + i of the image, q0 = 512 b + 8 lane: sample a of position q0 + k is T[4 + k + a]
-        uint32_t        T[32];
-        const uint32_t* p = static_cast<const uint32_t*>(__builtin_assume_aligned(&img[kImgBase + b * 512 + 8 * lane - 4], 16));
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-        {
-            const uint4 v = *reinterpret_cast<const uint4*>(p + 4 * i);
-            T[4 * i] = v.x; T[4 * i + 1] = v.y; T[4 * i + 2] = v.z; T[4 * i + 3] = v.w;
-        }
+        // eight 16-byte reads, written out: left to itself the compiler drops the three unused leading dwords and falls back to
+        // 13 misaligned 8-byte reads (lane stride 32 bytes: eight-way bank conflicts)
+        uint32_t       T[32];
+        const uint32_t addr = (uint32_t)(uintptr_t)&img[kImgBase + b * 512 + 8 * lane - 4];
+        uint4          v0, v1, v2, v3, v4, v5, v6, v7;
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+                     "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+                     : "v"(addr)
+                     : "memory");
+        T[0] = v0.x; T[1] = v0.y; T[2] = v0.z; T[3] = v0.w; T[4] = v1.x; T[5] = v1.y; T[6] = v1.z; T[7] = v1.w;
+        T[8] = v2.x; T[9] = v2.y; T[10] = v2.z; T[11] = v2.w; T[12] = v3.x; T[13] = v3.y; T[14] = v3.z; T[15] = v3.w;
+        T[16] = v4.x; T[17] = v4.y; T[18] = v4.z; T[19] = v4.w; T[20] = v5.x; T[21] = v5.y; T[22] = v5.z; T[23] = v5.w;
+        T[24] = v6.x; T[25] = v6.y; T[26] = v6.z; T[27] = v6.w; T[28] = v7.x; T[29] = v7.y; T[30] = v7.z; T[31] = v7.w;
         uint32_t P2[29]; // saturating pair sums s_a + s_a+1
 #pragma unroll
         for (int i = 3; i < 29; i++) P2[i] = pk_add_sat(T[i], T[i + 1]);
