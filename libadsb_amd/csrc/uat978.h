@@ -12,6 +12,7 @@ constexpr int kUatShortBytes  = 30;
 constexpr int kUatUplinkBytes = 552;
 constexpr int kUatUplinkBits  = kUatUplinkBytes * 8;
 constexpr uint32_t kUatDemodRanges = 64;
+constexpr uint8_t  kUatRecSkipped  = 0x80; // uat_rec_t::kind flag: not demodulated (the odd-sample twin of an even match)
 
 // one per 18-bit match, in candidate order; variant v = frame taken from sample index + v
 struct uat_rec_t

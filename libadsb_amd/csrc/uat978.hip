@@ -435,6 +435,96 @@ __device__ __forceinline__ void slice_frame(const uint16_t* __restrict__ in, con
     }
 }
 
+// ---- the demodulating wave works from a tile of phase differences in LDS: entry k = dphi(base + k) for k < kUatTileValid, zero
+// where the difference needs a sample beyond the stream.  One coalesced burst of 16-byte loads (two per lane) and, for IQ
+// input, sixteen independent LUT gathers per lane fill it; everything after that -- sign windows, both sync re-checks, both
+// slicings -- reads LDS instead of chasing sample -> LUT -> sample + 1 -> LUT through global memory per step.
+constexpr int kUatTile      = 1024; // samples staged (128 chunks of 8)
+constexpr int kUatTileValid = 1023; // the last entry would need the first phase of the next tile
+constexpr int kUatTileStride = 896; // uplink frames: tile t starts 896 t samples after the first (7 groups of 64 bits)
+
+template <bool PHASES_GIVEN>
+__device__ __noinline__ void stage_dphi(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n, uint64_t base,
+                                           int16_t* dphi_s, int lane)
+{
+    uint32_t   ph[2][8];
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+    {
+        const uint64_t s = base + 8ull * (uint64_t)(lane + 64 * r);
+        uint32_t       raw[8];
+        if (aligned && s + 8 <= n)
+        {
+            const uint4 x = *reinterpret_cast<const uint4*>(in + s);
+            raw[0] = x.x & 0xFFFFu, raw[1] = x.x >> 16, raw[2] = x.y & 0xFFFFu, raw[3] = x.y >> 16;
+            raw[4] = x.z & 0xFFFFu, raw[5] = x.z >> 16, raw[6] = x.w & 0xFFFFu, raw[7] = x.w >> 16;
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < 8; k++) raw[k] = (s + (uint64_t)k < n) ? in[s + (uint64_t)k] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) ph[r][k] = PHASES_GIVEN ? raw[k] : (uint32_t)lut[raw[k]];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+    {
+        const uint64_t s = base + 8ull * (uint64_t)(lane + 64 * r);
+        // the phase after a lane's eighth: the next lane's first; lane 63 of round 0 continues in lane 0 of round 1
+        const uint32_t wrap = r == 0 ? (uint32_t)__builtin_amdgcn_readlane((int)ph[1][0], 0) : 0u;
+        const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp((int)wrap, (int)ph[r][0], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+        uint32_t       d[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            const uint32_t to = k < 7 ? ph[r][k + 1] : next;
+            d[k]              = (s + (uint64_t)k + 1 < n) ? ((to - ph[r][k]) & 0xFFFFu) : 0u;
+        }
+        *reinterpret_cast<uint4*>(dphi_s + 8 * (lane + 64 * r)) = make_uint4(d[0] | d[1] << 16, d[2] | d[3] << 16, d[4] | d[5] << 16, d[6] | d[7] << 16);
+    }
+}
+
+// the sync re-check, the sign windows and the slicing on the staged tile; `off` = the first sample's index inside the tile
+__device__ __forceinline__ SyncCheck check_sync_tile(const int16_t* dphi_s, int off, bool uplink, int lane)
+{
+    static_assert(__builtin_popcountll(kAdsbSync) == 20 && __builtin_popcountll(kUplinkSync) == 16, "bits per class of the sync words");
+    const uint64_t pattern = uplink ? kUplinkSync : kAdsbSync;
+    const bool     in_sync = lane < 36;
+    const int      d       = in_sync ? (int)dphi_s[off + 2 * lane] : 0;
+    const bool     one     = in_sync && ((pattern >> ((35 - lane) & 63)) & 1ull);
+    const bool     zero    = in_sync && !one;
+    const int      one_tot = wave_sum_i(one ? d : 0), zero_tot = wave_sum_i(zero ? d : 0);
+    // C integer division by the class sizes (20 ones / 16 zeros in the ADS-B word, the reverse in the uplink word): constants, so
+    // no division sequence is emitted
+    const int one_mean = uplink ? one_tot / 16 : one_tot / 20, zero_mean = uplink ? zero_tot / 20 : zero_tot / 16;
+    SyncCheck r;
+    r.center       = (int)(int16_t)((one_mean + zero_mean) / 2);
+    const bool bad = (one && d < r.center) || (zero && d > r.center);
+    r.ok           = __builtin_popcountll(__ballot(bad)) <= 4;
+    return r;
+}
+__device__ __forceinline__ uint64_t sign_window_tile(const int16_t* dphi_s, int off, int lane)
+{
+    return __ballot(dphi_s[off + 2 * (lane & 31) + (lane >> 5)] > 0);
+}
+// frame bits 64 g .. 64 g + 63 (g in [g0, g1)) of a frame whose bit 0 sits at tile index off0; MSB-first bytes into out[]
+__device__ __forceinline__ void slice_groups_tile(const int16_t* dphi_s, int off0, int center, int nbits, int g0, int g1, uint8_t* out, int lane)
+{
+    for (int g = g0; g < g1; g++)
+    {
+        const int      gbase = 64 * g, bit = gbase + lane;
+        const int      d     = bit < nbits ? (int)dphi_s[off0 + 2 * bit] : 0;
+        const uint64_t bits  = __ballot(bit < nbits && d > center);
+        if (lane < 8 && gbase + 8 * lane < nbits)
+        {
+            const uint32_t byte      = (uint32_t)(bits >> (8 * lane)) & 0xFFu;
+            out[(gbase >> 3) + lane] = (uint8_t)(__builtin_bitreverse32(byte) >> 24);
+        }
+    }
+}
+
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"), __builtin_amdgcn_wave_barrier(), __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
 // ---- Reed-Solomon with the whole wave on one code word.  Same procedure and same results as rs978_decode_with_syndromes
@@ -459,6 +549,50 @@ __device__ __forceinline__ int wave_xor_i(int x)
 }
 __device__ __forceinline__ int      gf_fold(int x) { return (x & 255) + (x >> 8); } // == x mod 255 as an index into exp[] (< 510 for x < 65536)
 __device__ __forceinline__ uint32_t gf_mul(const RsTables& T, uint32_t a, uint32_t b) { return (a && b) ? T.exp[T.log[a] + T.log[b]] : 0u; }
+
+// The nr syndromes of the n symbols data[0], data[stride], ... with the wave across the symbols instead of Horner's n dependent
+// steps: S_i = sum_j data[j] alpha^((fcr + i)(n - 1 - j)); lane l takes symbols l and l + 64, four syndromes share one XOR
+// reduction (one byte of a dword each).  Same values as rs978_syndrome.  out[] is in LDS; the caller fences.
+__device__ __forceinline__ int mod255_16(int x)
+{ // x < 65536 -> congruent value in [0, 256]
+    x = (x & 255) + (x >> 8);
+    return (x & 255) + (x >> 8);
+}
+typedef __attribute__((address_space(3))) const uint8_t* lds_cu8; // kept out of line (registers), so the address space has to be spelled out
+typedef __attribute__((address_space(3))) uint8_t*       lds_u8;
+__device__ __noinline__ void syndromes_lds(lds_cu8 exp_t, lds_cu8 log_t, int nr, int n, lds_cu8 data, int stride, lds_u8 out, int lane)
+{
+    const bool     two = n > 64; // uniform
+    const int      j0 = lane, j1 = lane + 64;
+    const uint32_t d0 = j0 < n ? data[j0 * stride] : 0u, d1 = (two && j1 < n) ? data[j1 * stride] : 0u;
+    const int      l0 = log_t[d0], l1 = log_t[d1];
+    const uint32_t p0 = j0 < n ? (uint32_t)(n - 1 - j0) : 0u, p1 = j1 < n ? (uint32_t)(n - 1 - j1) : 0u; // < 255
+    // exponent of alpha^(root * p) for root = fcr, then + p per syndrome, kept below 255 (min with the wrapped difference)
+    uint32_t e0 = (uint32_t)mod255_16(kRsFcr * (int)p0), e1 = (uint32_t)mod255_16(kRsFcr * (int)p1);
+    e0 = __builtin_elementwise_min(e0, e0 - 255u), e1 = __builtin_elementwise_min(e1, e1 - 255u);
+    for (int i0 = 0; i0 < nr; i0 += 4)
+    {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            uint32_t term = d0 ? (uint32_t)exp_t[l0 + (int)e0] : 0u;
+            e0 += p0, e0 = __builtin_elementwise_min(e0, e0 - 255u);
+            if (two)
+            {
+                term ^= d1 ? (uint32_t)exp_t[l1 + (int)e1] : 0u;
+                e1 += p1, e1 = __builtin_elementwise_min(e1, e1 - 255u);
+            }
+            packed |= term << (8 * k);
+        }
+        const uint32_t red = (uint32_t)wave_xor_i((int)packed);
+        if (lane < 4 && i0 + lane < nr) out[i0 + lane] = (uint8_t)(red >> (8 * lane));
+    }
+}
+__device__ __forceinline__ void syndromes_wave(const RsTables& T, int nr, int n, const uint8_t* data, int stride, uint8_t* out, int lane)
+{
+    syndromes_lds((lds_cu8)T.exp, (lds_cu8)T.log, nr, n, (lds_cu8)data, stride, (lds_u8)out, lane);
+}
 
 __device__ int rs_decode_wave(const RsTables& T, int nr, int pad, uint8_t* data, int stride, RsWork& w, int lane)
 {
@@ -544,9 +678,8 @@ __device__ int rs_decode_wave(const RsTables& T, int nr, int pad, uint8_t* data,
     return count;
 }
 
-// correct_adsb_frame with the wave on one slicing: w.s = the 14 long syndromes, short_syn = the 12 short ones of the
-// untouched frame.  Returns the bits to jump (0 = neither); *rs = corrected symbols (9999 = neither).  Uniform.
-__device__ int correct_adsb_wave(const RsTables& T, uint8_t* frame48, RsWork& w, const uint8_t* short_syn, int lane, int* rs)
+// correct_adsb_frame with the wave on one slicing: w.s = the 14 long syndromes.  Returns the bits to jump (0 = neither); *rs = corrected symbols (9999 = neither).  Uniform.
+__device__ int correct_adsb_wave(const RsTables& T, uint8_t* frame48, RsWork& w, int lane, int* rs)
 {
     int n = rs_decode_wave(T, 14, 207, frame48, 1, w, lane);
     if (n >= 0 && n <= 7 && (frame48[0] >> 3) != 0)
@@ -554,7 +687,7 @@ __device__ int correct_adsb_wave(const RsTables& T, uint8_t* frame48, RsWork& w,
         *rs = n;
         return kUatLongSkip;
     }
-    if (lane < 12) w.s[lane] = n > 0 ? rs978_syndrome(T, lane, 30, frame48, 1) : short_syn[lane]; // the long attempt changed the frame iff n > 0
+    syndromes_wave(T, 12, 30, frame48, 1, w.s, lane); // only now: most frames are long and never get here
     wave_fence();
     n = rs_decode_wave(T, 12, 225, frame48, 1, w, lane);
     if (n >= 0 && n <= 6 && (frame48[0] >> 3) == 0)
@@ -590,7 +723,7 @@ __global__ __launch_bounds__(64) void uat_rs_selftest_kernel(const RsTables* __r
 }
 
 template <bool PHASES_GIVEN>
-__global__ __launch_bounds__(64, 8) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
+__global__ __launch_bounds__(64, 5) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
                                                        const RsTables* __restrict__ rs_tables, const uint32_t* __restrict__ cand, uint32_t ncand,
                                                        uat_rec_t* __restrict__ recs, uint8_t* __restrict__ uplink_payloads, uint32_t uplink_cap,
                                                        uint32_t* __restrict__ uplink_count, uint32_t* __restrict__ work_counters, uint32_t nranges)
@@ -598,7 +731,7 @@ __global__ __launch_bounds__(64, 8) void uat_demod_kernel(const uint16_t* __rest
     __shared__ RsTables T;
     __shared__ uint8_t  raw[2][kUatUplinkBytes + 8];
     __shared__ RsWork   work[12];
-    __shared__ uint8_t  short_syn[2][12];
+    __shared__ __attribute__((aligned(16))) int16_t dphi_s[kUatTile];
     const int lane = threadIdx.x;
     for (int i = lane; i < (int)sizeof(RsTables) / 4; i += 64) reinterpret_cast<uint32_t*>(&T)[i] = reinterpret_cast<const uint32_t*>(rs_tables)[i];
     wave_fence();
@@ -618,52 +751,89 @@ __global__ __launch_bounds__(64, 8) void uat_demod_kernel(const uint16_t* __rest
         const uint64_t idx  = word & 0x7FFFFFFFu;
         const uint64_t sb   = idx >> 1;
         uat_rec_t*     r    = &recs[c];
-        const uint64_t w0   = sign_window<PHASES_GIVEN>(in, lut, n, 2 * sb, lane);
-        const uint64_t w1   = sign_window<PHASES_GIVEN>(in, lut, n, 2 * (sb + (kind ? kUatUplinkSkip : kUatShortSkip) + 1), lane);
-        const uint64_t w2   = kind ? 0 : sign_window<PHASES_GIVEN>(in, lut, n, 2 * (sb + kUatLongSkip + 1), lane);
+        if ((word & 1u) && c > 0 && cand[c - 1] == word - 1u)
+        { // The same check word matched on the even sample of this bit too (the list is in stream order).  The scan loop looks at
+          // register 0 first, so it never takes this record; only a look-up after a jump could ask for it, and the host then has
+          // it demodulated on demand like any position that is not in the list.  Half of the matches of a frame-dense stream.
+            if (lane == 0) r->index = (uint32_t)idx, r->kind = (uint8_t)(kind | kUatRecSkipped);
+            c = first + nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)grabbed);
+            continue;
+        }
+        const uint64_t base = (2 * sb) & ~7ull;           // tile 0 starts here (16-byte aligned in the stream)
+        const int      o    = (int)(idx - base);          // the match's first sync sample inside tile 0 (0 .. 8)
+        const int      oe   = (int)(2 * sb - base);       // the same, forced even: what the two shift registers are aligned to
+        wave_fence(); // the previous candidate's readers are done with the tile
+        stage_dphi<PHASES_GIVEN>(in, lut, n, base, dphi_s, lane);
+        wave_fence();
+        const uint64_t w0 = sign_window_tile(dphi_s, oe, lane);
+        uint64_t       w1 = 0, w2 = 0;
         const int      nbits = kind ? kUatUplinkBits : kUatLongBytes * 8;
         bool           ok[2];
-#pragma unroll 1
+        int            center[2];
+#pragma unroll
         for (int v = 0; v < 2; v++)
         {
-            const SyncCheck sc = check_sync<PHASES_GIVEN>(in, lut, n, idx + (uint64_t)v, kind ? kUplinkSync : kAdsbSync, lane);
-            ok[v]              = sc.ok;
-            if (sc.ok) slice_frame<PHASES_GIVEN>(in, lut, n, idx + (uint64_t)v + 72, sc.center, nbits, raw[v], lane);
+            const SyncCheck sc = check_sync_tile(dphi_s, o + v, kind != 0, lane);
+            ok[v] = sc.ok, center[v] = sc.center;
+        }
+        if (kind == 0)
+        { // everything an ADS-B match needs lies in tile 0 (the last window ends 914 samples after its start)
+            w1 = sign_window_tile(dphi_s, oe + 2 * (kUatShortSkip + 1), lane);
+            w2 = sign_window_tile(dphi_s, oe + 2 * (kUatLongSkip + 1), lane);
+#pragma unroll
+            for (int v = 0; v < 2; v++)
+                if (ok[v]) slice_groups_tile(dphi_s, o + v + 72, center[v], nbits, 0, nbits / 64, raw[v], lane);
+        }
+        else if (ok[0] || ok[1])
+        { // an uplink frame spans ten tiles; group g of variant v starts at sample o + v + 72 + 128 g after the first tile's start
+            constexpr int kTiles = 10;
+            static_assert(72 + 9 + 128 * (kUatUplinkBits / 64 - 1) + 127 < kTiles * kUatTileStride + (kUatTileValid - kUatTileStride), "tiles cover the frame");
+            for (int t = 0; t < kTiles; t++)
+            {
+                if (t > 0)
+                {
+                    wave_fence();
+                    stage_dphi<PHASES_GIVEN>(in, lut, n, base + (uint64_t)(t * kUatTileStride), dphi_s, lane);
+                    wave_fence();
+                }
+#pragma unroll
+                for (int v = 0; v < 2; v++)
+                    if (ok[v])
+                    {
+                        const int first = o + v + 72; // of group 0, relative to tile 0
+                        int       g0 = (t * kUatTileStride - first + 127) / 128, g1 = ((t + 1) * kUatTileStride - first + 127) / 128;
+                        if (t == 0) g0 = 0;
+                        if (g1 > nbits / 64) g1 = nbits / 64;
+                        slice_groups_tile(dphi_s, first - t * kUatTileStride, center[v], nbits, g0, g1, raw[v], lane);
+                    }
+                const int after = oe + 2 * (kUatUplinkSkip + 1) - t * kUatTileStride; // the window behind the frame
+                if (after >= 0 && after + 64 < kUatTileValid && after < kUatTileStride) w1 = sign_window_tile(dphi_s, after, lane);
+            }
         }
         wave_fence();
-        // Reed-Solomon.  Syndromes first, one per lane (each is a Horner pass over the whole code word); then one lane per
-        // code word for the rest, which ends at once when its syndromes are all zero (2 lanes for ADS-B: one per slicing;
-        // 12 for an uplink frame: 2 x 6 interleaved blocks)
+        // Reed-Solomon.  Syndromes with the wave across the symbols, then the wave on one code word at a time, which ends at
+        // once when its syndromes are all zero
         int skip = 0, rs = 9999; // valid in lane v (ADS-B) / lane 6 v (uplink) afterwards
         if (kind == 0)
         {
-            { // lanes 0..27: the 14 long syndromes of slicing lane / 14; lanes 32..55: the 12 short ones of slicing (lane - 32) / 12
-                const bool is_long = lane < 28, is_short = lane >= 32 && lane < 56;
-                const int  v = is_long ? lane / 14 : (lane - 32) / 12, i = is_long ? lane % 14 : (lane - 32) % 12;
-                if ((is_long || is_short) && ok[v & 1])
-                {
-                    const uint8_t syn = rs978_syndrome(T, i, is_long ? 48 : 30, raw[v], 1);
-                    if (is_long) work[v].s[i] = syn;
-                    else short_syn[v][i] = syn;
-                }
-            }
+#pragma unroll 1
+            for (int v = 0; v < 2; v++)
+                if (ok[v]) syndromes_wave(T, 14, 48, raw[v], 1, work[v].s, lane);
             wave_fence();
 #pragma unroll 1
             for (int v = 0; v < 2; v++)
                 if (ok[v])
                 {
                     int       rs_v   = 9999;
-                    const int skip_v = correct_adsb_wave(T, raw[v], work[v], short_syn[v], lane, &rs_v);
+                    const int skip_v = correct_adsb_wave(T, raw[v], work[v], lane, &rs_v);
                     if (lane == v) skip = skip_v, rs = rs_v;
                 }
         }
         else
         {
-            for (int k = lane; k < 12 * 20; k += 64)
-            {
-                const int cw = k / 20, i = k % 20;
-                if (ok[cw / 6]) work[cw].s[i] = rs978_syndrome(T, i, 92, raw[cw / 6] + cw % 6, 6);
-            }
+#pragma unroll 1
+            for (int cw = 0; cw < 12; cw++)
+                if (ok[cw / 6]) syndromes_wave(T, 20, 92, raw[cw / 6] + cw % 6, 6, work[cw].s, lane);
             wave_fence();
 #pragma unroll 1
             for (int v = 0; v < 2; v++)

@@ -430,7 +430,8 @@ struct adsb_amd_uat
             size_t           q       = pos;
             for (; q < nordered && (int64_t)(rec_at(q).index >> 1) == startbit; q++)
             {
-                const uat_rec_t& r     = rec_at(q);
+                const uat_rec_t& r = rec_at(q);
+                if (r.kind & kUatRecSkipped) continue; // the odd twin of the even match just seen: never the loop's choice
                 m[r.kind][r.index & 1] = &r;
             }
             pos = q;
