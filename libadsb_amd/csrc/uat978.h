@@ -17,20 +17,20 @@ constexpr uint8_t  kUatRecSkipped  = 0x80; // uat_rec_t::kind flag: not demodula
 // one per 18-bit match, in candidate order; variant v = frame taken from sample index + v
 struct uat_rec_t
 {
-    uint32_t index;      // sample index of the first sync bit
-    uint8_t  kind;       // 0 = ADS-B sync word, 1 = uplink sync word
-    uint8_t  sync_ok[2]; // 36-bit sync re-check passed
+    uint32_t index;       // sample index of the first sync bit
+    int16_t  skip;        // bits the scan loop jumps when it takes this frame: 276 short, 420 long, 4452 uplink; 0 = no frame
+    uint8_t  rs;          // corrected symbols of the frame taken (uplink: sum over the six blocks); 255 = no frame
+    uint8_t  kind;        // 0 = ADS-B sync word, 1 = uplink sync word; | kUatRecSkipped
+    uint64_t window;      // sign bits from sample 2 * (index >> 1) on, low word = even samples (register 0), high word = odd
+                          // samples (register 1), bit k = k-th bit time: both 18-bit registers at detection time
+    uint64_t after;       // the same from bit (index >> 1) + skip + 1 on: what enters the registers after the jump
+    uint8_t  variant;     // the frame was taken from sample index + variant (the reference demodulates both and keeps the one
+                          // with fewer corrections, the first on a tie); 2 = neither decodes
     uint8_t  pad0;
-    int16_t  skip[2];    // bits the scan loop jumps when it takes this variant: 276 short, 420 long, 4452 uplink; 0 = no frame
-    int16_t  rs[2];      // corrected symbols (uplink: sum over the six blocks); 9999 = no frame
-    uint32_t slot[2];    // uplink: 432-byte slot of the decoded payload in the side array
-    uint32_t pad1;
-    uint64_t window;     // sign bits from sample 2 * (index >> 1) on, low word = even samples (register 0), high word = odd
-                         // samples (register 1), bit k = k-th bit time: both 18-bit registers at detection time
-    uint64_t after[2];   // the same from bit (index >> 1) + skip + 1 on: what enters the registers after the jump; [0] short / uplink, [1] long
-    uint8_t  payload[2][34 + 2]; // ADS-B: corrected frame bytes 0..33 (18 of them for a short frame)
+    uint8_t  payload[34]; // ADS-B: corrected frame bytes 0..33 (18 of them for a short frame)
+    uint32_t slot;        // uplink: 432-byte slot of the decoded payload in the side array
 };
-static_assert(sizeof(uat_rec_t) == 128, "record layout");
+static_assert(sizeof(uat_rec_t) == 64, "record layout");
 
 struct RsTables;
 

@@ -730,7 +730,7 @@ __global__ __launch_bounds__(64, 5) void uat_demod_kernel(const uint16_t* __rest
 {
     __shared__ RsTables T;
     __shared__ uint8_t  raw[2][kUatUplinkBytes + 8];
-    __shared__ RsWork   work[12];
+    __shared__ RsWork   work[6];
     __shared__ __attribute__((aligned(16))) int16_t dphi_s[kUatTile];
     const int lane = threadIdx.x;
     for (int i = lane; i < (int)sizeof(RsTables) / 4; i += 64) reinterpret_cast<uint32_t*>(&T)[i] = reinterpret_cast<const uint32_t*>(rs_tables)[i];
@@ -768,126 +768,113 @@ __global__ __launch_bounds__(64, 5) void uat_demod_kernel(const uint16_t* __rest
         const uint64_t w0 = sign_window_tile(dphi_s, oe, lane);
         uint64_t       w1 = 0, w2 = 0;
         const int      nbits = kind ? kUatUplinkBits : kUatLongBytes * 8;
-        bool           ok[2];
-        int            center[2];
-#pragma unroll
-        for (int v = 0; v < 2; v++)
-        {
-            const SyncCheck sc = check_sync_tile(dphi_s, o + v, kind != 0, lane);
-            ok[v] = sc.ok, center[v] = sc.center;
-        }
+        // frames from sample idx (variant 0) and idx + 1 (variant 1); all of this is wave-uniform.  The variant with fewer corrected
+        // symbols is taken and the first on a tie, so a variant 0 that decodes without corrections makes variant 1 irrelevant.
+        int skip0 = 0, skip1 = 0, rs0 = 9999, rs1 = 9999;
         if (kind == 0)
         { // everything an ADS-B match needs lies in tile 0 (the last window ends 914 samples after its start)
             w1 = sign_window_tile(dphi_s, oe + 2 * (kUatShortSkip + 1), lane);
             w2 = sign_window_tile(dphi_s, oe + 2 * (kUatLongSkip + 1), lane);
-#pragma unroll
+#pragma unroll 1
             for (int v = 0; v < 2; v++)
-                if (ok[v]) slice_groups_tile(dphi_s, o + v + 72, center[v], nbits, 0, nbits / 64, raw[v], lane);
-        }
-        else if (ok[0] || ok[1])
-        { // an uplink frame spans ten tiles; group g of variant v starts at sample o + v + 72 + 128 g after the first tile's start
-            constexpr int kTiles = 10;
-            static_assert(72 + 9 + 128 * (kUatUplinkBits / 64 - 1) + 127 < kTiles * kUatTileStride + (kUatTileValid - kUatTileStride), "tiles cover the frame");
-            for (int t = 0; t < kTiles; t++)
             {
-                if (t > 0)
-                {
-                    wave_fence();
-                    stage_dphi<PHASES_GIVEN>(in, lut, n, base + (uint64_t)(t * kUatTileStride), dphi_s, lane);
-                    wave_fence();
-                }
-#pragma unroll
-                for (int v = 0; v < 2; v++)
-                    if (ok[v])
-                    {
-                        const int first = o + v + 72; // of group 0, relative to tile 0
-                        int       g0 = (t * kUatTileStride - first + 127) / 128, g1 = ((t + 1) * kUatTileStride - first + 127) / 128;
-                        if (t == 0) g0 = 0;
-                        if (g1 > nbits / 64) g1 = nbits / 64;
-                        slice_groups_tile(dphi_s, first - t * kUatTileStride, center[v], nbits, g0, g1, raw[v], lane);
-                    }
-                const int after = oe + 2 * (kUatUplinkSkip + 1) - t * kUatTileStride; // the window behind the frame
-                if (after >= 0 && after + 64 < kUatTileValid && after < kUatTileStride) w1 = sign_window_tile(dphi_s, after, lane);
+                if (v == 1 && skip0 && rs0 == 0) break;
+                const SyncCheck sc = check_sync_tile(dphi_s, o + v, false, lane);
+                if (!sc.ok) continue;
+                slice_groups_tile(dphi_s, o + v + 72, sc.center, nbits, 0, nbits / 64, raw[v], lane);
+                wave_fence();
+                syndromes_wave(T, 14, 48, raw[v], 1, work[v].s, lane);
+                wave_fence();
+                int       rs_v   = 9999;
+                const int skip_v = correct_adsb_wave(T, raw[v], work[v], lane, &rs_v);
+                if (v == 0) skip0 = skip_v, rs0 = rs_v;
+                else skip1 = skip_v, rs1 = rs_v;
             }
-        }
-        wave_fence();
-        // Reed-Solomon.  Syndromes with the wave across the symbols, then the wave on one code word at a time, which ends at
-        // once when its syndromes are all zero
-        int skip = 0, rs = 9999; // valid in lane v (ADS-B) / lane 6 v (uplink) afterwards
-        if (kind == 0)
-        {
-#pragma unroll 1
-            for (int v = 0; v < 2; v++)
-                if (ok[v]) syndromes_wave(T, 14, 48, raw[v], 1, work[v].s, lane);
-            wave_fence();
-#pragma unroll 1
-            for (int v = 0; v < 2; v++)
-                if (ok[v])
-                {
-                    int       rs_v   = 9999;
-                    const int skip_v = correct_adsb_wave(T, raw[v], work[v], lane, &rs_v);
-                    if (lane == v) skip = skip_v, rs = rs_v;
-                }
         }
         else
         {
-#pragma unroll 1
-            for (int cw = 0; cw < 12; cw++)
-                if (ok[cw / 6]) syndromes_wave(T, 20, 92, raw[cw / 6] + cw % 6, 6, work[cw].s, lane);
-            wave_fence();
-#pragma unroll 1
+            bool ok[2];
+            int  center[2];
+#pragma unroll
             for (int v = 0; v < 2; v++)
-                if (ok[v])
-                { // correct_uplink_frame: every block within 10 corrections
+            {
+                const SyncCheck sc = check_sync_tile(dphi_s, o + v, true, lane);
+                ok[v] = sc.ok, center[v] = sc.center;
+            }
+            if (ok[0] || ok[1])
+            { // an uplink frame spans ten tiles; group g of variant v starts at sample o + v + 72 + 128 g after the first tile's start
+                constexpr int kTiles = 10;
+                static_assert(72 + 9 + 128 * (kUatUplinkBits / 64 - 1) + 127 < kTiles * kUatTileStride + (kUatTileValid - kUatTileStride), "tiles cover the frame");
+                for (int t = 0; t < kTiles; t++)
+                {
+                    if (t > 0)
+                    {
+                        wave_fence();
+                        stage_dphi<PHASES_GIVEN>(in, lut, n, base + (uint64_t)(t * kUatTileStride), dphi_s, lane);
+                        wave_fence();
+                    }
+#pragma unroll
+                    for (int v = 0; v < 2; v++)
+                        if (ok[v])
+                        {
+                            const int first = o + v + 72; // of group 0, relative to tile 0
+                            int       g0 = (t * kUatTileStride - first + 127) / 128, g1 = ((t + 1) * kUatTileStride - first + 127) / 128;
+                            if (t == 0) g0 = 0;
+                            if (g1 > nbits / 64) g1 = nbits / 64;
+                            slice_groups_tile(dphi_s, first - t * kUatTileStride, center[v], nbits, g0, g1, raw[v], lane);
+                        }
+                    const int after = oe + 2 * (kUatUplinkSkip + 1) - t * kUatTileStride; // the window behind the frame
+                    if (after >= 0 && after + 64 < kUatTileValid && after < kUatTileStride) w1 = sign_window_tile(dphi_s, after, lane);
+                }
+                wave_fence();
+#pragma unroll 1
+                for (int v = 0; v < 2; v++)
+                {
+                    if (!ok[v] || (v == 1 && skip0 && rs0 == 0)) continue;
+#pragma unroll 1
+                    for (int blk = 0; blk < 6; blk++) syndromes_wave(T, 20, 92, raw[v] + blk, 6, work[blk].s, lane);
+                    wave_fence();
+                    // correct_uplink_frame: every block within 10 corrections
                     int  total = 0;
                     bool good  = true;
 #pragma unroll 1
                     for (int blk = 0; blk < 6 && good; blk++)
                     {
-                        const int nb = rs_decode_wave(T, 20, 163, raw[v] + blk, 6, work[v * 6 + blk], lane);
+                        const int nb = rs_decode_wave(T, 20, 163, raw[v] + blk, 6, work[blk], lane);
                         good         = nb >= 0 && nb <= 10;
                         total += nb;
                     }
-                    if (good && lane == 6 * v) skip = kUatUplinkSkip, rs = total;
+                    if (good)
+                    {
+                        if (v == 0) skip0 = kUatUplinkSkip, rs0 = total;
+                        else skip1 = kUatUplinkSkip, rs1 = total;
+                    }
                 }
+            }
         }
         wave_fence();
-        const int src0 = 0, src1 = kind ? 6 : 1;
-        const int skip0 = __builtin_amdgcn_readlane(skip, src0), skip1 = __builtin_amdgcn_readlane(skip, src1);
-        const int rs0 = __builtin_amdgcn_readlane(rs, src0), rs1 = __builtin_amdgcn_readlane(rs, src1);
-        uint32_t slot[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (kind)
-        { // decoded uplink payloads go to a side array, one 432-byte slot each
-            const int want = (skip0 ? 1 : 0) + (skip1 ? 1 : 0);
-            if (want)
-            {
-                uint32_t first = 0;
-                if (lane == 0) first = atomicAdd(uplink_count, (uint32_t)want);
-                first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
-                if (skip0) slot[0] = first;
-                if (skip1) slot[1] = first + (skip0 ? 1u : 0u);
-#pragma unroll 1
-                for (int v = 0; v < 2; v++)
-                    if (slot[v] < uplink_cap)
-                        for (int k = lane; k < 432; k += 64) uplink_payloads[(size_t)slot[v] * 432 + k] = raw[v][(k % 72) * 6 + k / 72];
-            }
-        }
-        else
+        // the reference's choice between the two alignments (demod_*_frame at index and index + 1, fewer corrections wins, the first on a tie)
+        const int v_take = (skip0 && rs0 <= rs1) ? 0 : (skip1 && rs1 <= rs0) ? 1 : 2;
+        const int skip_t = v_take == 0 ? skip0 : v_take == 1 ? skip1 : 0, rs_t = v_take == 0 ? rs0 : rs1;
+        uint32_t  up_slot = 0xFFFFFFFFu;
+        if (v_take < 2)
         {
-            if (lane < 34)
-            {
-                if (skip0) r->payload[0][lane] = raw[0][lane];
-                if (skip1) r->payload[1][lane] = raw[1][lane];
+            if (kind)
+            { // the decoded uplink payload goes to a side array, one 432-byte slot per frame
+                uint32_t got = 0;
+                if (lane == 0) got = atomicAdd(uplink_count, 1u);
+                up_slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                if (up_slot < uplink_cap)
+                    for (int k = lane; k < 432; k += 64) uplink_payloads[(size_t)up_slot * 432 + k] = raw[v_take][(k % 72) * 6 + k / 72];
             }
+            else if (lane < 34) r->payload[lane] = raw[v_take][lane];
         }
         if (lane == 0)
         {
-            r->index = (uint32_t)idx, r->kind = (uint8_t)kind;
-            r->sync_ok[0] = ok[0], r->sync_ok[1] = ok[1];
-            r->skip[0] = (int16_t)skip0, r->skip[1] = (int16_t)skip1;
-            r->rs[0] = (int16_t)rs0, r->rs[1] = (int16_t)rs1;
-            r->slot[0] = slot[0], r->slot[1] = slot[1];
-            r->window = w0, r->after[0] = w1, r->after[1] = w2;
+            r->index = (uint32_t)idx, r->kind = (uint8_t)kind, r->variant = (uint8_t)v_take;
+            r->skip = (int16_t)skip_t, r->rs = (uint8_t)(v_take < 2 ? rs_t : 255);
+            r->slot = up_slot, r->window = w0;
+            r->after = (kind || skip_t == kUatShortSkip) ? w1 : w2; // what enters the registers after the jump
         }
         wave_fence(); // raw[] is reused by the next candidate
         c = first + nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)grabbed);

@@ -279,7 +279,7 @@ struct adsb_amd_uat
             }
             stat_candidates += ncand;
             const double t1 = now_ms();
-            rc = reserve_uplink(2 * ncand + 64); // at most two decoded payloads per match
+            rc = reserve_uplink(ncand + 64); // at most one decoded payload per match
             if (rc) return rc;
             { // stream order on the device, so that the records arrive in the order the scan loop walks them
                 const size_t words = 2 * (size_t)((n + 32767) / 32768) + 2; // launch_uat978_order: two words per 32 768-sample bin
@@ -353,7 +353,7 @@ struct adsb_amd_uat
             *out = ex->second;
             return ADSB_AMD_OK;
         }
-        if (nrecords + 1 > cand_cap || nuplink + 2 > up_cap)
+        if (nrecords + 1 > cand_cap || nuplink + 1 > up_cap)
         { // replace the device arrays by larger ones (host copies are complete); the slot counter keeps counting
             int            rc      = reserve_cand(cand_cap * 2 + 64);
             if (!rc) rc = reserve_uplink(up_cap * 2 + 64);
@@ -379,24 +379,20 @@ struct adsb_amd_uat
         const uint8_t* data = nullptr;
     };
 
-    // demod_*_frame at index and index + 1 happened on the device; this is the reference's choice between them
+    // demod_*_frame at index and index + 1, and the reference's choice between them, happened on the device
     bool attempt(const uat_rec_t& r, Attempt& best) const
     {
-        const int skip0 = r.skip[0], skip1 = r.skip[1], rs0 = r.rs[0], rs1 = r.rs[1];
-        int       v;
-        if (skip0 && rs0 <= rs1) v = 0;
-        else if (skip1 && rs1 <= rs0) v = 1;
-        else return false;
-        best.skip = r.skip[v], best.rs = r.rs[v], best.variant = v;
+        if (r.variant > 1) return false;
+        best.skip = r.skip, best.rs = r.rs, best.variant = r.variant;
         if (r.kind)
         {
             best.len  = 432;
-            best.data = up_h.p + (size_t)r.slot[v] * 432;
+            best.data = up_h.p + (size_t)r.slot * 432;
         }
         else
         {
-            best.len  = (r.payload[v][0] >> 3) == 0 ? 18 : 34;
-            best.data = r.payload[v];
+            best.len  = (r.payload[0] >> 3) == 0 ? 18 : 34;
+            best.data = r.payload;
         }
         return true;
     }
@@ -448,7 +444,7 @@ struct adsb_amd_uat
             // --- jump: bit = startbit + skip, then the loop's ++.  The registers keep their contents, so for the next 17 bits
             // they mix bits from before the jump with new ones and can fire where the stream itself has no match.
             uint32_t oldw[2] = {(uint32_t)r->window & kCheckMask, (uint32_t)(r->window >> 32) & kCheckMask};
-            uint64_t fresh   = (r->kind || a.skip == kUatShortSkip) ? r->after[0] : r->after[1];
+            uint64_t fresh   = r->after;
             bit              = startbit + a.skip + 1;
             for (;;)
             {
@@ -481,7 +477,7 @@ struct adsb_amd_uat
                     if (!attempt(r2, a2)) continue;
                     emit(r2, a2);
                     oldw[0] = w0, oldw[1] = w1;
-                    fresh   = (r2.kind || a2.skip == kUatShortSkip) ? r2.after[0] : r2.after[1];
+                    fresh   = r2.after;
                     bit     = sb2 + a2.skip + 1;
                     jumped  = true;
                     break;
