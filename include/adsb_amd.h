@@ -281,6 +281,13 @@ int adsb_amd_uat_process_phases(adsb_amd_uat_t* u, const uint16_t* phi_host, uin
                                 int64_t* consumed);
 int adsb_amd_uat_process_iq(adsb_amd_uat_t* u, const void* iq, uint64_t nsamples, int on_device, uint64_t offset, adsb_amd_uat_frame_fn cb,
                             void* user, int64_t* consumed);
+/* The same in two halves, for streams already in HBM: submit starts the GPU half (match search, ordering, per-match
+ * demodulation and Reed-Solomon, records to the host) on a worker thread and returns; collect waits for the oldest submitted call and
+ * runs the scan loop with its up-calls on the caller's thread.  Two calls may be in flight (each on its own stream and buffers), so
+ * the GPU half of call k + 1 overlaps the scan loop of call k; a third submit returns ADSB_AMD_ESTATE.  The input of a call must stay
+ * valid until it is collected.  Results are identical to adsb_amd_uat_process_iq call by call. */
+int adsb_amd_uat_submit_iq(adsb_amd_uat_t* u, const void* iq_device, uint64_t nsamples, uint64_t offset);
+int adsb_amd_uat_collect(adsb_amd_uat_t* u, adsb_amd_uat_frame_fn cb, void* user, int64_t* consumed);
 /* device time of the last process call (sign+match kernels, demod kernel) and running totals of 18-bit matches and of
  * positions the host had to ask the device about on top of those */
 int adsb_amd_uat_timing(const adsb_amd_uat_t* u, float* scan_ms, float* demod_ms, uint64_t* candidates, uint64_t* extra_lookups);

@@ -38,7 +38,7 @@ EXPORTS = [
     "adsb_amd_transport_create", "adsb_amd_transport_destroy", "adsb_amd_transport_start", "adsb_amd_transport_stop", "adsb_amd_transport_push",
     "adsb_amd_transport_stats",
     "adsb_amd_uat_create", "adsb_amd_uat_destroy", "adsb_amd_uat_last_error", "adsb_amd_uat_handle_data", "adsb_amd_uat_set_carry_full",
-    "adsb_amd_uat_stream_state", "adsb_amd_uat_process_phases", "adsb_amd_uat_process_iq", "adsb_amd_uat_timing", "adsb_amd_uat_host_timing", "adsb_amd_uat_phase_lut",
+    "adsb_amd_uat_stream_state", "adsb_amd_uat_process_phases", "adsb_amd_uat_process_iq", "adsb_amd_uat_submit_iq", "adsb_amd_uat_collect", "adsb_amd_uat_timing", "adsb_amd_uat_host_timing", "adsb_amd_uat_phase_lut",
     "adsb_amd_uat_rs_decode", "adsb_amd_uat_rs_decode_device", "adsb_amd_uat_set_dump_raw_message", "init_fec", "process_buffer",
 ]
 
@@ -124,6 +124,8 @@ def lib():
         L.adsb_amd_uat_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.adsb_amd_uat_phase_lut.argtypes = [C.c_void_p, C.c_void_p]
         L.adsb_amd_uat_host_timing.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 4
+        L.adsb_amd_uat_submit_iq.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        L.adsb_amd_uat_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.adsb_amd_uat_rs_decode.argtypes = [C.c_int, C.c_void_p]
         L.adsb_amd_uat_rs_decode_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.adsb_amd_uat_set_dump_raw_message.argtypes = [C.c_void_p]
@@ -497,6 +499,16 @@ class Uat978:
         out, done = [], C.c_int64()
         cb = self._collector(out) if collect else None
         self._check(self._l.adsb_amd_uat_process_iq(self._h, C.c_void_p(device_ptr), nsamples, 1, offset, cb, None, C.byref(done)))
+        return out, done.value
+
+    def submit_device(self, device_ptr, nsamples, offset=0):
+        """GPU half of process_device on a worker thread (two calls may be in flight); collect() finishes the oldest."""
+        self._check(self._l.adsb_amd_uat_submit_iq(self._h, C.c_void_p(device_ptr), nsamples, offset))
+
+    def collect(self, collect=True):
+        out, done = [], C.c_int64()
+        cb = self._collector(out) if collect else None
+        self._check(self._l.adsb_amd_uat_collect(self._h, cb, None, C.byref(done)))
         return out, done.value
 
     def timing(self):

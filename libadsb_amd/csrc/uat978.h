@@ -44,7 +44,8 @@ struct UatArgs
     uint64_t*       signs; // phases path only: ceil(nsamples / 64) + 2 words
     uint32_t*       cand;
     uint32_t        cand_cap;
-    uint32_t*       counts; // [0] candidates, [1] uplink payload slots
+    uint32_t*       counts; // [0] candidates, [1] uplink payload slots, [2] uplink matches (set by the ordering pass)
+    uint32_t*       up_list; // cand_cap entries: positions of the uplink matches in the ordered list
     uat_rec_t*      recs;   // cand_cap entries
     uint8_t*        uplink_payloads; // uplink_cap x 432 bytes
     uint32_t        uplink_cap;
@@ -52,7 +53,7 @@ struct UatArgs
 };
 
 hipError_t launch_uat978(const UatArgs& a, hipStream_t stream);                       // signs + 18-bit match
-hipError_t launch_uat978_order(const uint32_t* cand, uint32_t ncand, uint64_t nsamples, uint32_t* scratch, uint32_t* sorted, hipStream_t stream);
-hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, hipStream_t stream); // one wave per candidate
+hipError_t launch_uat978_order(const UatArgs& a, uint32_t ncand, uint32_t* scratch, uint32_t* sorted, hipStream_t stream);
+hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, bool ordered, hipStream_t stream); // one wave per candidate
 hipError_t launch_uat978_rs_selftest(const RsTables* tables, int kind, uint8_t* words, int* results, int count, hipStream_t stream);
 } // namespace adsb_amd

@@ -726,7 +726,8 @@ template <bool PHASES_GIVEN>
 __global__ __launch_bounds__(64, 5) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
                                                        const RsTables* __restrict__ rs_tables, const uint32_t* __restrict__ cand, uint32_t ncand,
                                                        uat_rec_t* __restrict__ recs, uint8_t* __restrict__ uplink_payloads, uint32_t uplink_cap,
-                                                       uint32_t* __restrict__ uplink_count, uint32_t* __restrict__ work_counters, uint32_t nranges)
+                                                       uint32_t* __restrict__ uplink_count, uint32_t* __restrict__ work_counters, uint32_t nranges,
+                                                       const uint32_t* __restrict__ up_list, const uint32_t* __restrict__ up_count)
 {
     __shared__ RsTables T;
     __shared__ uint8_t  raw[2][kUatUplinkBytes + 8];
@@ -741,22 +742,31 @@ __global__ __launch_bounds__(64, 5) void uat_demod_kernel(const uint16_t* __rest
     // is cut into `nranges` pieces, each with a counter on its own cache line; a block takes its first candidate by position.
     const uint32_t range = blockIdx.x % nranges, slot = blockIdx.x / nranges, nslot = gridDim.x / nranges;
     const uint32_t per   = (ncand + nranges - 1) / nranges;
-    const uint32_t first = range * per, end = first + per < ncand ? first + per : ncand;
-    for (uint32_t c = first + slot; c < end;)
+    const uint32_t first = range * per < ncand ? range * per : ncand, end = first + per < ncand ? first + per : ncand;
+    // Uplink matches first (up_list, dealt round-robin to the ranges), then the range's own slice of the list with the uplink
+    // entries passed over.  up_list == nullptr (single look-ups): plain order.
+    const uint32_t nup    = up_list ? *up_count : 0u;
+    const uint32_t nup_r  = nup > range ? (nup - range + nranges - 1) / nranges : 0u;
+    const uint32_t nitems = nup_r + (end - first);
+    for (uint32_t item = slot; item < nitems;)
     {
         uint32_t grabbed = 0;
         if (lane == 0) grabbed = atomicAdd(&work_counters[range * 32u], 1u); // used at the end of the trip
+        const uint32_t next_item = nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)grabbed);
+        const bool     from_list = item < nup_r;
+        const uint32_t c         = from_list ? up_list[range + item * nranges] : first + (item - nup_r);
+        item                     = next_item;
         const uint32_t word = cand[c];
         const uint32_t kind = word >> 31;
         const uint64_t idx  = word & 0x7FFFFFFFu;
         const uint64_t sb   = idx >> 1;
         uat_rec_t*     r    = &recs[c];
+        if (!from_list && kind && up_list) continue; // an uplink match inside the slice: taken in the first phase
         if ((word & 1u) && c > 0 && cand[c - 1] == word - 1u)
         { // The same check word matched on the even sample of this bit too (the list is in stream order).  The scan loop looks at
           // register 0 first, so it never takes this record; only a look-up after a jump could ask for it, and the host then has
           // it demodulated on demand like any position that is not in the list.  Half of the matches of a frame-dense stream.
             if (lane == 0) r->index = (uint32_t)idx, r->kind = (uint8_t)(kind | kUatRecSkipped);
-            c = first + nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)grabbed);
             continue;
         }
         const uint64_t base = (2 * sb) & ~7ull;           // tile 0 starts here (16-byte aligned in the stream)
@@ -877,7 +887,6 @@ __global__ __launch_bounds__(64, 5) void uat_demod_kernel(const uint16_t* __rest
             r->after = (kind || skip_t == kUatShortSkip) ? w1 : w2; // what enters the registers after the jump
         }
         wave_fence(); // raw[] is reused by the next candidate
-        c = first + nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)grabbed);
     }
 }
 // ---- ordering: the matches come out of the search in whatever order the waves flushed them; the host walks them in stream
@@ -892,9 +901,12 @@ __global__ __launch_bounds__(256) void uat_order_count_kernel(const uint32_t* __
 }
 
 // exclusive prefix of span_count[0 .. nspans) in place; one workgroup, every lane owns a contiguous slice
-__global__ __launch_bounds__(1024) void uat_order_prefix_kernel(uint32_t* __restrict__ span_count, uint32_t nspans)
+__global__ __launch_bounds__(1024) void uat_order_prefix_kernel(uint32_t* __restrict__ span_count, uint32_t nspans, uint32_t* __restrict__ demod_work,
+                                                                uint32_t* __restrict__ up_count)
 {
     __shared__ uint32_t partial[1024];
+    if (threadIdx.x < kUatDemodRanges) demod_work[threadIdx.x * 32u] = 0; // the demodulation pass that follows starts from zero
+    if (threadIdx.x == 0) *up_count = 0;
     const uint32_t      per = (nspans + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < nspans ? lo + per : nspans;
     uint32_t            sum = 0;
     for (uint32_t k = lo; k < hi; k++) sum += span_count[k];
@@ -928,12 +940,13 @@ __global__ __launch_bounds__(256) void uat_order_scatter_kernel(const uint32_t* 
 }
 
 __global__ __launch_bounds__(256) void uat_order_within_kernel(const uint32_t* __restrict__ span_offset, const uint32_t* __restrict__ span_fill,
-                                                               uint32_t nspans, uint32_t* __restrict__ sorted)
+                                                               uint32_t nspans, uint32_t* __restrict__ sorted, uint32_t* __restrict__ up_list,
+                                                               uint32_t* __restrict__ up_count)
 {
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nspans; s += gridDim.x * blockDim.x)
     {
         const uint32_t n = span_fill[s];
-        if (n < 2) continue;
+        if (n == 0) continue;
         uint32_t* a = sorted + span_offset[s];
         for (uint32_t i = 1; i < n; i++)
         { // by sample index; two entries never share one (the check words are complements)
@@ -942,6 +955,10 @@ __global__ __launch_bounds__(256) void uat_order_within_kernel(const uint32_t* _
             for (; j > 0 && (a[j - 1] & 0x7FFFFFFFu) > key; j--) a[j] = a[j - 1];
             a[j] = v;
         }
+        // positions of the uplink matches: the demodulation pass takes these first (they cost ten times an ADS-B match, and one
+        // that starts last would be the kernel's tail)
+        for (uint32_t i = 0; i < n; i++)
+            if (a[i] >> 31) up_list[atomicAdd(up_count, 1u)] = span_offset[s] + i;
     }
 }
 
@@ -970,38 +987,46 @@ hipError_t launch_uat978(const UatArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, hipStream_t stream)
+// ordered: the list is the output of launch_uat978_order on the same stream (which also zeroed the work counters and collected
+// the uplink positions, a.up_list / a.counts + 2); otherwise a handful of look-ups the host asked for
+hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, bool ordered, hipStream_t stream)
 {
     if (ncand == 0) return hipSuccess;
     const uint32_t nranges = ncand >= 4096 ? kUatDemodRanges : 1u;
     uint32_t       g       = ncand > 8192 ? 8192 : ncand;
     g                      = ((g + nranges - 1) / nranges) * nranges;
-    hipError_t e = hipMemsetAsync(a.demod_work, 0, kUatDemodRanges * 32 * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
+    if (!ordered)
+    {
+        hipError_t e = hipMemsetAsync(a.demod_work, 0, kUatDemodRanges * 32 * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t* up_list  = ordered ? a.up_list : nullptr;
+    const uint32_t* up_count = ordered ? a.counts + 2 : nullptr;
     if (a.phases_given)
         hipLaunchKernelGGL(uat_demod_kernel<true>, dim3(g), dim3(64), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
-                           a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges);
+                           a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges, up_list, up_count);
     else
         hipLaunchKernelGGL(uat_demod_kernel<false>, dim3(g), dim3(64), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
-                           a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges);
+                           a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges, up_list, up_count);
     return hipGetLastError();
 }
 
-// cand[0 .. ncand) -> sorted[0 .. ncand) by sample index.  scratch: 2 * nspans words, nspans = spans covering nsamples.
-hipError_t launch_uat978_order(const uint32_t* cand, uint32_t ncand, uint64_t nsamples, uint32_t* scratch, uint32_t* sorted, hipStream_t stream)
+// a.cand[0 .. ncand) -> sorted[0 .. ncand) by sample index; positions of the uplink matches in `sorted` -> a.up_list, their number ->
+// a.counts[2]; the demodulation work counters zeroed.  scratch: 2 * nspans words, nspans = spans covering a.nsamples.
+hipError_t launch_uat978_order(const UatArgs& a, uint32_t ncand, uint32_t* scratch, uint32_t* sorted, hipStream_t stream)
 {
     if (ncand == 0) return hipSuccess;
-    const uint32_t nspans = (uint32_t)((nsamples + (1u << kUatOrderSpanShift) - 1) >> kUatOrderSpanShift);
+    const uint32_t nspans = (uint32_t)((a.nsamples + (1u << kUatOrderSpanShift) - 1) >> kUatOrderSpanShift);
     uint32_t*      offset = scratch;
     uint32_t*      fill   = scratch + nspans;
     hipError_t     e      = hipMemsetAsync(scratch, 0, 2 * (size_t)nspans * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     const uint32_t gc = (ncand + 255) / 256 > 1024 ? 1024 : (ncand + 255) / 256;
     const uint32_t gs = (nspans + 255) / 256 > 1024 ? 1024 : (nspans + 255) / 256;
-    hipLaunchKernelGGL(uat_order_count_kernel, dim3(gc), dim3(256), 0, stream, cand, ncand, offset);
-    hipLaunchKernelGGL(uat_order_prefix_kernel, dim3(1), dim3(1024), 0, stream, offset, nspans);
-    hipLaunchKernelGGL(uat_order_scatter_kernel, dim3(gc), dim3(256), 0, stream, cand, ncand, offset, fill, sorted);
-    hipLaunchKernelGGL(uat_order_within_kernel, dim3(gs), dim3(256), 0, stream, offset, fill, nspans, sorted);
+    hipLaunchKernelGGL(uat_order_count_kernel, dim3(gc), dim3(256), 0, stream, a.cand, ncand, offset);
+    hipLaunchKernelGGL(uat_order_prefix_kernel, dim3(1), dim3(1024), 0, stream, offset, nspans, a.demod_work, a.counts + 2);
+    hipLaunchKernelGGL(uat_order_scatter_kernel, dim3(gc), dim3(256), 0, stream, a.cand, ncand, offset, fill, sorted);
+    hipLaunchKernelGGL(uat_order_within_kernel, dim3(gs), dim3(256), 0, stream, offset, fill, nspans, sorted, a.up_list, a.counts + 2);
     return hipGetLastError();
 }
 

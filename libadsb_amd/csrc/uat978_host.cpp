@@ -22,6 +22,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <condition_variable>
 #include <unordered_map>
 #include <vector>
 
@@ -70,6 +72,37 @@ constexpr uint32_t stale_steps(uint32_t oldw, uint32_t x)
 constexpr uint32_t kStaleSteps[2][2] = {{stale_steps(kCheckT[0], kCheckT[0]), stale_steps(kCheckT[0], kCheckT[1])},
                                         {stale_steps(kCheckT[1], kCheckT[0]), stale_steps(kCheckT[1], kCheckT[1])}};
 constexpr uint32_t kAllSteps = 0x3FFFEu; // t = 1 .. 17
+
+// Which of the 17 steps after a jump can fire at all, from two bytes of the register's 35-bit history X = old | new << 18
+// (step t looks at bits t .. t + 17 of X): bits 17 .. 24 lie inside the window of every t >= 8, bits 7 .. 14 inside that of
+// every t <= 7, so each byte rules out every step whose check word disagrees with it.  Random data leaves a step standing
+// with probability 2^-8; the survivors are compared in full.  (Replaces 17 x 4 full comparisons per emitted frame.)
+struct StepFilter
+{
+    uint32_t hi[2][256], lo[2][256]; // [check word][byte] -> steps t consistent with it
+};
+constexpr StepFilter make_step_filter()
+{
+    StepFilter f{};
+    for (int p = 0; p < 2; p++)
+        for (uint32_t v = 0; v < 256; v++)
+        {
+            uint32_t hi = 0, lo = 0;
+            for (int t = 8; t <= 17; t++)
+                if (((kCheckT[p] >> (17 - t)) & 0xFFu) == v) hi |= 1u << t;
+            for (int t = 1; t <= 7; t++)
+                if (((kCheckT[p] >> (7 - t)) & 0xFFu) == v) lo |= 1u << t;
+            f.hi[p][v] = hi, f.lo[p][v] = lo;
+        }
+    return f;
+}
+constexpr StepFilter kStepFilter = make_step_filter();
+inline uint32_t possible_steps(uint32_t oldw, uint32_t fresh)
+{
+    const uint64_t x  = (uint64_t)oldw | ((uint64_t)fresh << 18);
+    const uint32_t b1 = (uint32_t)(x >> 17) & 0xFFu, b0 = (uint32_t)(x >> 7) & 0xFFu;
+    return kStepFilter.hi[0][b1] | kStepFilter.lo[0][b0] | kStepFilter.hi[1][b1] | kStepFilter.lo[1][b0];
+}
 
 #define UAT_HIP(expr)                                                        \
     do                                                                       \
@@ -158,6 +191,7 @@ struct adsb_amd_uat
 
     ~adsb_amd_uat()
     {
+        stop_pipeline();
         (void)hipSetDevice(device);
         for (void* p : {(void*)lut_d, (void*)rs_d, (void*)signs_d, (void*)cand_d, (void*)sorted_d, (void*)order_scratch_d, (void*)counts_d, (void*)demod_work_d, (void*)recs_d, (void*)up_d, (void*)in_d,
                         (void*)stage_d, (void*)stage_tmp_d})
@@ -186,7 +220,7 @@ struct adsb_amd_uat
         UAT_HIP(hipMemcpy(lut_d, lut_h.data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice));
         UAT_HIP(hipMalloc(&rs_d, sizeof(RsTables)));
         UAT_HIP(hipMemcpy(rs_d, &rs_tables(), sizeof(RsTables), hipMemcpyHostToDevice));
-        UAT_HIP(hipMalloc(&counts_d, 2 * sizeof(uint32_t)));
+        UAT_HIP(hipMalloc(&counts_d, 4 * sizeof(uint32_t)));
         UAT_HIP(hipMalloc(&demod_work_d, kUatDemodRanges * 32 * sizeof(uint32_t)));
         UAT_HIP(hipHostMalloc(&counts_h, 4 * sizeof(uint32_t))); // [0] matches, [1] uplink slots, [2] one look-up request
         UAT_HIP(hipMalloc(&stage_d, 65536 * sizeof(uint16_t)));
@@ -248,6 +282,7 @@ struct adsb_amd_uat
         a.in = in, a.lut = lut_d, a.rs_tables = rs_d, a.nsamples = n, a.phases_given = phases_given ? 1 : 0;
         a.signs = signs_d, a.cand = cand_d, a.cand_cap = cand_cap, a.counts = counts_d; // demod_on_device points a.cand at sorted_d
         a.recs = recs_d, a.uplink_payloads = up_d, a.uplink_cap = up_cap, a.demod_work = demod_work_d;
+        a.up_list = order_scratch_d ? order_scratch_d + 2 * (size_t)((n + 32767) / 32768) + 2 : nullptr;
         return a;
     }
 
@@ -282,7 +317,7 @@ struct adsb_amd_uat
             rc = reserve_uplink(ncand + 64); // at most one decoded payload per match
             if (rc) return rc;
             { // stream order on the device, so that the records arrive in the order the scan loop walks them
-                const size_t words = 2 * (size_t)((n + 32767) / 32768) + 2; // launch_uat978_order: two words per 32 768-sample bin
+                const size_t words = 2 * (size_t)((n + 32767) / 32768) + 2 + cand_cap; // launch_uat978_order: two words per 32 768-sample bin, then the uplink positions
                 if (words > order_scratch_words)
                 {
                     if (order_scratch_d) (void)hipFree(order_scratch_d);
@@ -290,9 +325,9 @@ struct adsb_amd_uat
                     UAT_HIP(hipMalloc(&order_scratch_d, words * sizeof(uint32_t)));
                     order_scratch_words = words;
                 }
-                UAT_HIP(launch_uat978_order(cand_d, ncand, n, order_scratch_d, sorted_d, stream));
+                UAT_HIP(launch_uat978_order(args(in_dev, n, phases_given), ncand, order_scratch_d, sorted_d, stream));
             }
-            rc = demod_on_device(in_dev, n, phases_given, ncand, 0);
+            rc = demod_on_device(in_dev, n, phases_given, ncand, 0, true);
             if (rc) return rc;
             nmain = ncand;
             UAT_HIP(hipEventElapsedTime(&scan_ms, ev[0], ev[1]));
@@ -303,7 +338,7 @@ struct adsb_amd_uat
     }
 
     // run K3 over sorted_d[first .. first + count) and append the records to recs_h / up_h
-    int demod_on_device(const uint16_t* in_dev, uint64_t n, bool phases_given, uint32_t count, uint32_t first)
+    int demod_on_device(const uint16_t* in_dev, uint64_t n, bool phases_given, uint32_t count, uint32_t first, bool ordered)
     {
         if (count == 0) return ADSB_AMD_OK;
         UatArgs a = args(in_dev, n, phases_given);
@@ -311,7 +346,7 @@ struct adsb_amd_uat
         a.recs += first;
         UAT_HIP(recs_h.reserve((size_t)first + count, first));
         UAT_HIP(hipEventRecord(ev[2], stream));
-        UAT_HIP(launch_uat978_demod(a, count, stream));
+        UAT_HIP(launch_uat978_demod(a, count, ordered, stream));
         UAT_HIP(hipEventRecord(ev[3], stream));
         UAT_HIP(hipMemcpyAsync(counts_h + 1, counts_d + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         UAT_HIP(hipMemcpyAsync(recs_h.p + first, recs_d + first, (size_t)count * sizeof(uat_rec_t), hipMemcpyDeviceToHost, stream));
@@ -363,7 +398,7 @@ struct adsb_amd_uat
         UAT_HIP(hipMemcpyAsync(sorted_d + nrecords, counts_h + 2, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         stat_extra++;
         const uint32_t at = nrecords;
-        int            rc = demod_on_device(in_dev, n, phases_given, 1, at);
+        int            rc = demod_on_device(in_dev, n, phases_given, 1, at, false);
         if (rc) return rc;
         extra[((uint64_t)index << 1) | kind] = at;
         *out                                 = at;
@@ -402,6 +437,14 @@ struct adsb_amd_uat
     {
         int rc = scan(in_dev, len, phases_given);
         if (rc) return rc;
+        return scan_loop(in_dev, len, phases_given, stream_offset, cb, user, consumed);
+    }
+
+    // the host half of process(): the scan loop over the records scan() left in recs_h
+    int scan_loop(const uint16_t* in_dev, uint64_t len, bool phases_given, uint64_t stream_offset, adsb_amd_uat_frame_fn cb, void* user,
+                  int64_t* consumed)
+    {
+        int           rc      = ADSB_AMD_OK;
         const double  t_loop  = now_ms();
         const int64_t lenbits = (int64_t)(len / 2) - (kUatSyncBits + kUatUplinkBits);
 
@@ -454,6 +497,7 @@ struct adsb_amd_uat
                     steps |= oldw[g] == kCheckT[0] ? (kStaleSteps[0][0] | kStaleSteps[0][1])
                                                    : oldw[g] == kCheckT[1] ? (kStaleSteps[1][0] | kStaleSteps[1][1]) : kAllSteps;
                 const uint32_t newb[2] = {(uint32_t)fresh, (uint32_t)(fresh >> 32)};
+                steps &= possible_steps(oldw[0], newb[0]) | possible_steps(oldw[1], newb[1]);
                 bool           jumped  = false;
                 while (steps)
                 {
@@ -494,6 +538,118 @@ struct adsb_amd_uat
         *consumed = lenbits > 0 ? (bit - kUatCheckBits) * 2 : (int64_t)-2 * kUatCheckBits;
         wall_ms[3] = (float)(now_ms() - t_loop);
         return ADSB_AMD_OK;
+    }
+
+    // ---------------------------------------------------------------------------------------------------------------
+    // Two calls in flight on device-resident input: the GPU half of call k + 1 (scan, ordering, demodulation, records to the
+    // host) runs on a worker thread while the caller's thread walks the records of call k.  Every call owns a full set of
+    // buffers and a stream: this object and its twin take the calls alternately.
+    // ---------------------------------------------------------------------------------------------------------------
+    struct Job
+    {
+        const uint16_t* in = nullptr;
+        uint64_t        n = 0, offset = 0;
+        int             rc = 0;
+        bool            queued = false, done = false;
+    };
+    std::unique_ptr<adsb_amd_uat> twin;
+    std::thread                   worker;
+    std::mutex                    pipe_mu;
+    std::condition_variable       pipe_cv;
+    Job                           jobs[2];       // [0] runs on this object, [1] on the twin
+    uint64_t                      submitted = 0, collected = 0;
+    bool                          pipe_stop = false;
+
+    adsb_amd_uat* side(uint64_t k) { return (k & 1) ? twin.get() : this; }
+
+    void worker_loop()
+    {
+        (void)hipSetDevice(device);
+        uint64_t next = 0; // jobs are taken in submission order
+        for (;;)
+        {
+            Job* j = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(pipe_mu);
+                pipe_cv.wait(lk, [&] { return pipe_stop || (next < submitted && jobs[next & 1].queued); });
+                if (pipe_stop) return;
+                j = &jobs[next & 1];
+            }
+            const int rc = side(next)->scan(j->in, j->n, false);
+            {
+                std::lock_guard<std::mutex> lk(pipe_mu);
+                j->rc = rc, j->queued = false, j->done = true;
+            }
+            pipe_cv.notify_all();
+            next++;
+        }
+    }
+
+    int submit(const uint16_t* in_dev, uint64_t n, uint64_t stream_offset)
+    {
+        if (submitted - collected >= 2) return fail(ADSB_AMD_ESTATE, "two UAT calls are in flight already: collect one first");
+        if (!twin)
+        {
+            twin.reset(new adsb_amd_uat());
+            twin->device = device;
+            const int rc = twin->init();
+            if (rc)
+            {
+                error = twin->error;
+                twin.reset();
+                return rc;
+            }
+        }
+        if (!worker.joinable()) worker = std::thread([this] { worker_loop(); });
+        {
+            std::lock_guard<std::mutex> lk(pipe_mu);
+            Job& j = jobs[submitted & 1];
+            j.in = in_dev, j.n = n, j.offset = stream_offset, j.rc = 0, j.done = false, j.queued = true;
+            submitted++;
+        }
+        pipe_cv.notify_all();
+        return ADSB_AMD_OK;
+    }
+
+    int collect(adsb_amd_uat_frame_fn cb, void* user, int64_t* consumed)
+    {
+        if (collected == submitted) return fail(ADSB_AMD_ESTATE, "no UAT call in flight");
+        Job j;
+        {
+            std::unique_lock<std::mutex> lk(pipe_mu);
+            pipe_cv.wait(lk, [&] { return jobs[collected & 1].done; });
+            j = jobs[collected & 1];
+        }
+        adsb_amd_uat* s = side(collected);
+        collected++;
+        if (j.rc)
+        {
+            if (s != this) error = s->error;
+            return j.rc;
+        }
+        const int rc = s->scan_loop(j.in, j.n, false, j.offset, cb, user, consumed);
+        if (s != this)
+        { // statistics and timings are reported through the handle the caller holds
+            error = s->error;
+            scan_ms = s->scan_ms, demod_ms = s->demod_ms;
+            std::memcpy(wall_ms, s->wall_ms, sizeof(wall_ms));
+            stat_candidates += s->stat_candidates, stat_extra += s->stat_extra;
+            s->stat_candidates = s->stat_extra = 0;
+        }
+        return rc;
+    }
+
+    void stop_pipeline()
+    {
+        if (worker.joinable())
+        {
+            {
+                std::lock_guard<std::mutex> lk(pipe_mu);
+                pipe_stop = true;
+            }
+            pipe_cv.notify_all();
+            worker.join();
+        }
     }
 
     int upload(const void* host, size_t nbytes)
@@ -615,6 +771,19 @@ extern "C" int adsb_amd_uat_process_iq(adsb_amd_uat_t* u, const void* iq, uint64
     }
     else if (reinterpret_cast<uintptr_t>(iq) & 15u) return u->fail(ADSB_AMD_EINVAL, "device IQ pointer must be 16-byte aligned");
     return u->process(dev, nsamples, false, offset, cb, user, consumed);
+}
+extern "C" int adsb_amd_uat_submit_iq(adsb_amd_uat_t* u, const void* iq_device, uint64_t nsamples, uint64_t offset)
+{
+    if (!u || (!iq_device && nsamples)) return ADSB_AMD_EINVAL;
+    if (reinterpret_cast<uintptr_t>(iq_device) & 15u) return u->fail(ADSB_AMD_EINVAL, "device IQ pointer must be 16-byte aligned");
+    if (hipSetDevice(u->device) != hipSuccess) return u->fail(ADSB_AMD_EHIP, "hipSetDevice failed");
+    return u->submit(reinterpret_cast<const uint16_t*>(iq_device), nsamples, offset);
+}
+extern "C" int adsb_amd_uat_collect(adsb_amd_uat_t* u, adsb_amd_uat_frame_fn cb, void* user, int64_t* consumed)
+{
+    if (!u || !consumed) return ADSB_AMD_EINVAL;
+    if (hipSetDevice(u->device) != hipSuccess) return u->fail(ADSB_AMD_EHIP, "hipSetDevice failed");
+    return u->collect(cb, user, consumed);
 }
 extern "C" int adsb_amd_uat_timing(const adsb_amd_uat_t* u, float* scan_ms, float* demod_ms, uint64_t* candidates, uint64_t* extra_lookups)
 {

@@ -149,6 +149,33 @@ def test_device_resident_input(uat):
     assert t["scan_ms"] > 0
 
 
+def test_two_calls_in_flight_equal_the_serial_calls(native_libs):
+    """submit / collect: the GPU half of call k + 1 runs while the scan loop of call k walks its records; frames and consumed
+    counts call by call as process_iq gives them (and as the oracle does), a third submit is refused."""
+    import torch
+    u = A.Uat978()
+    streams = [synth.fill978(40 + k, (4 + 2 * k) * 1024 * 1024, synth.default_cfg978(**over))
+               for k, over in enumerate(({}, {"pct_uplink": 40}, {"mean_gap_bits": 40, "pct_corrupt": 60}, {}, {"noise_amp": 6}))]
+    dev = [torch.from_numpy(x).cuda() for x in streams]
+    torch.cuda.synchronize()
+    want = [u.process_device(d.data_ptr(), x.size // 2, offset=1000 * k) for k, (d, x) in enumerate(zip(dev, streams))]
+    assert want[0] == O.process_buffer978(O.phase_lut978()[streams[0].view(np.uint16)])
+    got = []
+    u.submit_device(dev[0].data_ptr(), streams[0].size // 2, 0)
+    for k in range(len(streams)):
+        if k + 1 < len(streams):
+            u.submit_device(dev[k + 1].data_ptr(), streams[k + 1].size // 2, 1000 * (k + 1))
+            if k == 0:
+                with pytest.raises(A.AdsbAmdError):
+                    u.submit_device(dev[2].data_ptr(), streams[2].size // 2, 0)
+        got.append(u.collect())
+    assert got == want
+    with pytest.raises(A.AdsbAmdError):
+        u.collect()
+    assert u.process_device(dev[1].data_ptr(), streams[1].size // 2, offset=1000) == want[1]  # the plain call still works afterwards
+    u.close()
+
+
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_device_reed_solomon_matches_oracle_including_beyond_capacity(uat, kind):
     """The wave-wide decoder inside the demod kernel, on its own: clean, correctable, uncorrectable and random words."""
