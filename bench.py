@@ -578,10 +578,11 @@ def bench_uat978(args, rank, local_rank, world, dist, A, synth, torch):
     nframes = len(frames)
 
     def run_pipelined(steps):
-        """two calls in flight: the GPU half of step k + 1 (worker thread, second stream and buffer set) under the scan loop of step k"""
-        u.submit_device(dev.data_ptr(), nsamples)
+        """three calls in flight: the GPU halves of steps k + 1 and k + 2 (worker threads, own streams and buffer sets) under the scan loop of step k"""
+        for k in range(min(2, steps)):
+            u.submit_device(dev.data_ptr(), nsamples)
         for k in range(steps):
-            if k + 1 < steps:
+            if k + 2 < steps:
                 u.submit_device(dev.data_ptr(), nsamples)
             u.collect(collect=False)
 

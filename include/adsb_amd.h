@@ -283,8 +283,8 @@ int adsb_amd_uat_process_iq(adsb_amd_uat_t* u, const void* iq, uint64_t nsamples
                             void* user, int64_t* consumed);
 /* The same in two halves, for streams already in HBM: submit starts the GPU half (match search, ordering, per-match
  * demodulation and Reed-Solomon, records to the host) on a worker thread and returns; collect waits for the oldest submitted call and
- * runs the scan loop with its up-calls on the caller's thread.  Two calls may be in flight (each on its own stream and buffers), so
- * the GPU half of call k + 1 overlaps the scan loop of call k; a third submit returns ADSB_AMD_ESTATE.  The input of a call must stay
+ * runs the scan loop with its up-calls on the caller's thread.  Three calls may be in flight (each on its own stream and buffers), so
+ * the GPU halves of calls k + 1 and k + 2 overlap the scan loop of call k; a fourth submit returns ADSB_AMD_ESTATE.  The input of a call must stay
  * valid until it is collected.  Results are identical to adsb_amd_uat_process_iq call by call. */
 int adsb_amd_uat_submit_iq(adsb_amd_uat_t* u, const void* iq_device, uint64_t nsamples, uint64_t offset);
 int adsb_amd_uat_collect(adsb_amd_uat_t* u, adsb_amd_uat_frame_fn cb, void* user, int64_t* consumed);

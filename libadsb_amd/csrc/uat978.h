@@ -12,7 +12,6 @@ constexpr int kUatShortBytes  = 30;
 constexpr int kUatUplinkBytes = 552;
 constexpr int kUatUplinkBits  = kUatUplinkBytes * 8;
 constexpr uint32_t kUatDemodRanges = 64;
-constexpr uint8_t  kUatRecSkipped  = 0x80; // uat_rec_t::kind flag: not demodulated (the odd-sample twin of an even match)
 
 // one per 18-bit match, in candidate order; variant v = frame taken from sample index + v
 struct uat_rec_t
@@ -20,7 +19,7 @@ struct uat_rec_t
     uint32_t index;       // sample index of the first sync bit
     int16_t  skip;        // bits the scan loop jumps when it takes this frame: 276 short, 420 long, 4452 uplink; 0 = no frame
     uint8_t  rs;          // corrected symbols of the frame taken (uplink: sum over the six blocks); 255 = no frame
-    uint8_t  kind;        // 0 = ADS-B sync word, 1 = uplink sync word; | kUatRecSkipped
+    uint8_t  kind;        // 0 = ADS-B sync word, 1 = uplink sync word
     uint64_t window;      // sign bits from sample 2 * (index >> 1) on, low word = even samples (register 0), high word = odd
                           // samples (register 1), bit k = k-th bit time: both 18-bit registers at detection time
     uint64_t after;       // the same from bit (index >> 1) + skip + 1 on: what enters the registers after the jump

@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void uat_match_kernel(const uint64_t* __restri
             accU &= ((kUplinkSync >> (35 - k)) & 1ull) ? v : ~v;
         }
         // the window of a match at sample i ends at i + 34 and the difference needs sample i + 35
+        accA &= ~((accA << 1) & 0xAAAAAAAAu), accU &= ~((accU << 1) & 0xAAAAAAAAu); // odd twin of an even match: never the loop's choice (see uat_scan_iq_kernel)
         uint32_t hits = accA | accU;
         while (hits)
         {
@@ -320,7 +321,12 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
                 all &= x;
                 any |= x;
             }
-            uint32_t hits = all | ~any; // ADS-B word: every bit agrees; uplink word: none does
+            // A check word that matches on the even sample of a bit time and again on the odd one: the scan loop looks at register 0
+            // first and never takes the second match, so it is dropped here (a word starts on an even sample: the twin is the next
+            // bit of the same mask).  Only a look-up after a jump can still ask for it; the host has it demodulated on demand then.
+            uint32_t none = ~any;
+            all &= ~((all << 1) & 0xAAAAAAAAu), none &= ~((none << 1) & 0xAAAAAAAAu);
+            uint32_t hits = all | none; // ADS-B word: every bit agrees; uplink word: none does
             if (hits)
             {
                 const uint64_t word_start = s0 + (uint64_t)lane * 32;
@@ -762,13 +768,6 @@ __global__ __launch_bounds__(64, 5) void uat_demod_kernel(const uint16_t* __rest
         const uint64_t sb   = idx >> 1;
         uat_rec_t*     r    = &recs[c];
         if (!from_list && kind && up_list) continue; // an uplink match inside the slice: taken in the first phase
-        if ((word & 1u) && c > 0 && cand[c - 1] == word - 1u)
-        { // The same check word matched on the even sample of this bit too (the list is in stream order).  The scan loop looks at
-          // register 0 first, so it never takes this record; only a look-up after a jump could ask for it, and the host then has
-          // it demodulated on demand like any position that is not in the list.  Half of the matches of a frame-dense stream.
-            if (lane == 0) r->index = (uint32_t)idx, r->kind = (uint8_t)(kind | kUatRecSkipped);
-            continue;
-        }
         const uint64_t base = (2 * sb) & ~7ull;           // tile 0 starts here (16-byte aligned in the stream)
         const int      o    = (int)(idx - base);          // the match's first sync sample inside tile 0 (0 .. 8)
         const int      oe   = (int)(2 * sb - base);       // the same, forced even: what the two shift registers are aligned to

@@ -149,9 +149,9 @@ def test_device_resident_input(uat):
     assert t["scan_ms"] > 0
 
 
-def test_two_calls_in_flight_equal_the_serial_calls(native_libs):
+def test_calls_in_flight_equal_the_serial_calls(native_libs):
     """submit / collect: the GPU half of call k + 1 runs while the scan loop of call k walks its records; frames and consumed
-    counts call by call as process_iq gives them (and as the oracle does), a third submit is refused."""
+    counts call by call as process_iq gives them (and as the oracle does), a fourth submit is refused."""
     import torch
     u = A.Uat978()
     streams = [synth.fill978(40 + k, (4 + 2 * k) * 1024 * 1024, synth.default_cfg978(**over))
@@ -161,13 +161,14 @@ def test_two_calls_in_flight_equal_the_serial_calls(native_libs):
     want = [u.process_device(d.data_ptr(), x.size // 2, offset=1000 * k) for k, (d, x) in enumerate(zip(dev, streams))]
     assert want[0] == O.process_buffer978(O.phase_lut978()[streams[0].view(np.uint16)])
     got = []
-    u.submit_device(dev[0].data_ptr(), streams[0].size // 2, 0)
+    for k in range(2):
+        u.submit_device(dev[k].data_ptr(), streams[k].size // 2, 1000 * k)
     for k in range(len(streams)):
-        if k + 1 < len(streams):
-            u.submit_device(dev[k + 1].data_ptr(), streams[k + 1].size // 2, 1000 * (k + 1))
+        if k + 2 < len(streams):
+            u.submit_device(dev[k + 2].data_ptr(), streams[k + 2].size // 2, 1000 * (k + 2))
             if k == 0:
-                with pytest.raises(A.AdsbAmdError):
-                    u.submit_device(dev[2].data_ptr(), streams[2].size // 2, 0)
+                with pytest.raises(A.AdsbAmdError):  # three in flight: no fourth
+                    u.submit_device(dev[3].data_ptr(), streams[3].size // 2, 0)
         got.append(u.collect())
     assert got == want
     with pytest.raises(A.AdsbAmdError):
