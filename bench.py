@@ -168,7 +168,8 @@ def main():
                 u = bench_uat978(argparse.Namespace(**{**vars(args), "steps": max(5, min(args.steps, 30)), "warmup": min(args.warmup, 3)}),
                                  0, local_rank, 1, None, A, synth, torch)
                 out["uat978"] = {k: u[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "frames_per_step",
-                                                   "demod_kernel_ms", "matches_per_step_rank0", "host_wall_ms_last_step", "cpu_baseline") if k in u}
+                                                   "demod_kernel_ms", "dominant_kernel", "matches_per_step_rank0", "pipelined", "ms_per_step_serial",
+                                                   "host_wall_ms_last_step", "cpu_baseline") if k in u}
             except Exception as e:  # the headline line must not be lost to the second workload
                 out["uat978"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
@@ -300,7 +301,7 @@ def bench_1090_single(args, local_rank, A, synth, torch):
                 "kernel_ms": round(k24 / 50, 4), "roofline_frac": round((2.0 * samples + 32.0 * len(r24)) / (k24 / 50 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "records_per_step": int(len(r24)), "frames_injected": int(inj24), "accepted_frames": int(acc24),
                 "note": "PARITY UNPINNED: 1 GiB of the generator's pulse trains sampled at 2.4 MS/s through ADSB_AMD_MODE_2400 (specification "
-                        "oracle/oracle2400.c; no reference demodulator for this rate exists, SURVEY.md F3/F5); first version of the kernel, not tuned"}
+                        "oracle/oracle2400.c; no reference demodulator for this rate exists, SURVEY.md F3/F5); kernel by part and what is left to do: DESIGN.md section 11"}
             sc24.close()
             del d24, iq24
         except Exception as e:
@@ -629,10 +630,13 @@ def bench_uat978(args, rank, local_rank, world, dist, A, synth, torch):
             "host_wall_ms_last_step": tm["host_wall_ms"],
         }
         if demod_k > scan_k:
-            # latency-bound per-match kernel: its algorithmic bytes are the phases of the matches' frames, far below any HBM bound
+            # per-match kernel, instruction-bound (PMC: 1 400 VALU + 820 SALU per match): its algorithmic bytes are the phases of the
+            # matches' frames, far below any HBM bound
             out["dominant_kernel"] = {"kernel": "uat_demod_kernel", "kernel_ms": round(demod_k, 4), "matches": int(matches),
                                       "us_per_1000_matches": round(demod_k * 1e3 / max(1, matches) * 1e3, 2),
-                                      "note": "latency-bound (dependent Reed-Solomon steps per match), not bandwidth-bound; the HBM roofline above is the scan kernel's"}
+                                      "note": "dominant by time; instruction-bound (sync re-check, slicing, Reed-Solomon per match: about 1 400 vector + 820 scalar "
+                                              "instructions per match, profiles/r02_uat978_rocprof_summary.txt), not bandwidth-bound: the HBM roofline "
+                                              "above is the scan kernel's, the only kernel of this path that streams the input"}
         if world == 1 and args.cpu_buffers > 0:
             from oracle import oracle_py as O
             phi = O.phase_lut978()[first.view(np.uint16)]
