@@ -34,7 +34,7 @@ constexpr int kSpan24     = 292;                          // samples after j a c
 constexpr int kHalo24     = 320;                          // halo dwords of the image (>= kSpan24, a multiple of 8)
 constexpr int kImgBase    = 4;                            // dword of the image's q = 0; dword 3 = (sample before the chunk | s[2047] << 16)
 constexpr int kImgDwords  = kImgBase + kHalfChunk + kHalo24 + 4;
-constexpr int kQueue24    = 256;
+constexpr int kQueue24    = 128;                          // queue entries per pass (a lane holds at most 64)
 constexpr int kWinSamples = 296;                          // magnitudes kept per candidate (t = 0 .. 295, 292 used)
 
 __device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b)
@@ -181,15 +181,17 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
 {
     __shared__ __attribute__((aligned(16))) uint32_t img[kImgDwords];
     __shared__ uint16_t                              mwin[kWinSamples + 8];
-    __shared__ uint16_t                              queue[kQueue24];
+    __shared__ uint16_t                              queue[kQueue24], wlist[kQueue24];
+    __shared__ uint32_t                              score[kQueue24];
     uint16_t* const                                  img16 = reinterpret_cast<uint16_t*>(img);
 
     const int        lane = threadIdx.x;
     const LaneTables lt   = load_lane_tables(a.crc_tab, lane);
     // preamble weights of this lane (see the candidate loop)
     const int tl = lane & 15, rw = lane >> 4;
-    const int wp = tl < 13 ? (int)kPreamble.p[rw][tl] : 0;
-    const int wq = rw == 0 ? (tl < 13 ? (int)kPreamble.p[4][tl] : 0) : (rw == 1 && tl >= 1 && tl <= 11 ? 1 : 0);
+    int       wpk = 0; // the five phases' weights of window sample tl, four bits each (signed, -5 .. 5)
+    if (tl < 13)
+        for (int k = 0; k < 5; k++) wpk |= ((int)kPreamble.p[k][tl] & 15) << (4 * k);
     if (blockIdx.x == 0 && lane < 2) total_overflow[lane] = 0; // {record total, overflow flag}: filled by the ordering pass that follows in-stream
 
     // persistent waves, chunk order and work counters as in scan1090_kernel (scan_common.hip.h)
@@ -306,48 +308,97 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     e.base  = reinterpret_cast<uint4*>(a.chunk_records + (uint64_t)me * a.cap);
     e.cap   = a.cap;
     e.count = 0;
-    for (uint32_t base = 0; base < n1; base += (uint32_t)kQueue24)
+    // A pass takes whole lanes (a lane's survivors of one 8-position group are consecutive queue entries in ascending position, so
+    // a run never straddles two passes) until kQueue24 entries are full.
+    const uint32_t excl = incl - mine;
+    for (uint32_t base = 0; base < n1;)
     {
+        const uint64_t over = ballot(excl >= base && incl > base + (uint32_t)kQueue24);
+        uint32_t       next_base = n1;
+        int            last_lane = 64; // lanes base-lane .. last_lane - 1 are in
+        if (over)
+        {
+            last_lane = __builtin_ctzll(over);
+            next_base = (uint32_t)__builtin_amdgcn_readlane((int)excl, last_lane);
+        }
+        const uint32_t nq = next_base - base; // <= kQueue24; > 0 because a lane holds at most 64
+        if (excl >= base && lane < last_lane)
         {
             uint64_t sv  = surv;
-            uint32_t idx = incl - mine;
+            uint32_t idx = excl - base;
             while (sv)
             {
                 const int bit = __builtin_ctzll(sv);
                 sv &= sv - 1;
-                if (idx - base < (uint32_t)kQueue24) queue[idx - base] = (uint16_t)(kHalfChunk * ((bit >> 3) & 1) + 512 * (bit >> 4) + 8 * lane + (bit & 7));
-                idx++;
+                queue[idx++] = (uint16_t)(kHalfChunk * ((bit >> 3) & 1) + 512 * (bit >> 4) + 8 * lane + (bit & 7));
             }
         }
         wave_lds_fence();
-        const uint32_t nq = (n1 - base < (uint32_t)kQueue24) ? (n1 - base) : (uint32_t)kQueue24;
-        for (uint32_t t = 0; t < nq; t++)
+        // ---- preamble scores, four candidates per trip: row r of 16 lanes takes entry t + r, lane 16 r + i holds sample i of its window
+        // (13 of them matter); five weighted row sums give P(phi), lane 15 of the row keeps the best (first of equals) and stores
+        // best << 3 | phi, or 0 when no phase correlates (P <= 0): most gate survivors of noise.
+        for (uint32_t t = 0; t < nq; t += 4)
         {
-            const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)queue[t]);
-            const uint32_t a0  = 2u * (uint32_t)kImgBase + 2u * (pos & (uint32_t)(kHalfChunk - 1)) + (pos >> 11); // half of sample t = 0
-            // preamble correlation first, on registers: lane 16 r + t holds sample t (13 of them matter) for phase r = 0..3 in wp;
-            // wq carries phase 4 in row 0 and the plain sum of samples 1..11 in row 1.  Most gate survivors of noise end here.
-            const int m  = mag_of_s(img16[a0 + 2 * (lane & 15)]);
-            const int vp = row_scan_add(wp * m), vq = row_scan_add(wq * m);
-            int best = __builtin_amdgcn_readlane(vp, 15), phi_star = 0;
+            const uint32_t q   = t + (uint32_t)rw;
+            const uint32_t pos = queue[q < nq ? q : nq - 1];
+            const uint32_t a0  = 2u * (uint32_t)kImgBase + 2u * (pos & (uint32_t)(kHalfChunk - 1)) + (pos >> 11);
+            const int      m   = mag_of_s(img16[a0 + 2 * tl]);
+            int            best = row_scan_add(__builtin_amdgcn_sbfe(wpk, 0, 4) * m), phi = 0;
+#pragma unroll
+            for (int k = 1; k < 5; k++)
             {
-                const int p1 = __builtin_amdgcn_readlane(vp, 31), p2 = __builtin_amdgcn_readlane(vp, 47), p3 = __builtin_amdgcn_readlane(vp, 63),
-                          p4 = __builtin_amdgcn_readlane(vq, 15);
-                if (p1 > best) best = p1, phi_star = 1;
-                if (p2 > best) best = p2, phi_star = 2;
-                if (p3 > best) best = p3, phi_star = 3;
-                if (p4 > best) best = p4, phi_star = 4;
+                const int p = row_scan_add(__builtin_amdgcn_sbfe(wpk, 4 * k, 4) * m);
+                if (p > best) best = p, phi = k;
             }
-            if (best <= 0) continue;
+            if (tl == 15 && q < nq) score[q] = best > 0 ? ((uint32_t)best << 3) | (uint32_t)phi : 0u;
+        }
+        wave_lds_fence();
+        // ---- one candidate per run: entry q stands for its run (gate survivors at consecutive positions inside one group of 8) when
+        // its score is positive, larger than every earlier member's and not smaller than any later member's
+        uint32_t nw = 0;
+        for (uint32_t r0 = 0; r0 < nq; r0 += 64)
+        {
+            const uint32_t q   = r0 + (uint32_t)lane;
+            const bool     in  = q < nq;
+            const uint32_t pos = in ? queue[q] : 0u;
+            const uint32_t sc  = in ? score[q] >> 3 : 0u;
+            bool           win = sc > 0u, run = true;
+#pragma unroll
+            for (uint32_t k = 1; k < 8; k++)
+            { // earlier members
+                run = run && k <= (pos & 7u) && q >= k && queue[q - k] == pos - k;
+                if (run && (score[q - k] >> 3) >= sc) win = false;
+            }
+            run = true;
+#pragma unroll
+            for (uint32_t k = 1; k < 8; k++)
+            { // later members
+                run = run && (pos & 7u) + k < 8u && q + k < nq && queue[q + k] == pos + k;
+                if (run && (score[q + k] >> 3) > sc) win = false;
+            }
+            const uint64_t wins = ballot(win);
+            if (win) wlist[nw + (uint32_t)__builtin_popcountll(wins & ((1ull << lane) - 1ull))] = (uint16_t)q;
+            nw += (uint32_t)__builtin_popcountll(wins);
+        }
+        wave_lds_fence();
 #if defined(ADSB_AMD_PARTS24) && ADSB_AMD_PARTS24 == 2
-            if (best != 0x12345678) continue;
+        if (nw != 0x12345678u) nw = 0;
 #endif
-            // pulse energy of the winning phase: pulse - quiet = P and pulse + quiet = the samples' overlap with [phi, phi + 60) fifths,
-            // which is 5 (s1 + .. + s11) + (5 - phi) s0 + phi s12
-            const int total = 5 * __builtin_amdgcn_readlane(vq, 31) + (5 - phi_star) * __builtin_amdgcn_readlane(m, 0) + phi_star * __builtin_amdgcn_readlane(m, 12);
-            const int amp   = ((best + total) >> 1) / 24;
+        // ---- the candidates, one at a time with the whole wave
+        for (uint32_t w = 0; w < nw; w++)
+        {
+            const uint32_t q        = (uint32_t)__builtin_amdgcn_readfirstlane((int)wlist[w]);
+            const uint32_t pos      = (uint32_t)__builtin_amdgcn_readfirstlane((int)queue[q]);
+            const uint32_t packed   = (uint32_t)__builtin_amdgcn_readfirstlane((int)score[q]);
+            const int      phi_star = (int)(packed & 7u), best = (int)(packed >> 3);
+            const uint32_t a0       = 2u * (uint32_t)kImgBase + 2u * (pos & (uint32_t)(kHalfChunk - 1)) + (pos >> 11); // half of sample t = 0
             wave_lds_fence(); // the previous candidate's readers are done with mwin
             window_magnitudes(mwin, img16, a0, lane, 0, 2);
+            // pulse energy of the winning phase: pulse - quiet = P and pulse + quiet = the samples' overlap with [phi, phi + 60) fifths,
+            // which is 5 (s1 + .. + s11) + (5 - phi) s0 + phi s12
+            const int wt    = lane == 0 ? 5 - phi_star : lane == 12 ? phi_star : lane < 12 ? 5 : 0;
+            const int total = (int)wave_sum((uint32_t)(wt * (int)mwin[lane < 13 ? lane : 0]));
+            const int amp   = ((best + total) >> 1) / 24;
             bool have_tail = false;
             if (slice_and_emit(mwin, img16, a0, have_tail, lane, lt, e, g0 + pos, phi_star, amp)) continue;
 #if defined(ADSB_AMD_PARTS24) && ADSB_AMD_PARTS24 == 3
@@ -357,6 +408,7 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
             if (phi_star - 1 >= 0) (void)slice_and_emit(mwin, img16, a0, have_tail, lane, lt, e, g0 + pos, phi_star - 1, amp);
         }
         wave_lds_fence();
+        base = next_base;
     }
     if (lane == 0) a.chunk_counts[me] = e.count;
 

@@ -28,6 +28,8 @@
  *   message   DF = bits 0..4, length by DF as in the reference (:295-299); rejected when more than nbits/8 bits are weak;
  *             DF11/17: accepted with zero syndrome, or with a single-bit repair (first bit in ascending order, :304-332) when at most
  *             two bits are weak; DF0/4/5/16/20/21/24: conditional record carrying AP xor parity (:396-435) when at most four bits are weak
+ *   runs      a frame passes the gate at two or three neighbouring positions.  Gate survivors at consecutive positions form a run (runs are
+ *             cut at multiples of 8 positions); only the member with the largest P(phi*) > 0 -- the first such -- is a candidate
  *   phases    tried in the order phi*, phi*+1, phi*-1 (inside 0..4); the first accepted slice is the candidate's record
  *   scan      j = 0 .. N - 293 of each buffer (the longest window is 19.2 + 268.8 + 1 samples; 292 samples after j are read)
  */
@@ -133,13 +135,13 @@ typedef struct record2400
     uint8_t  msg[14];
 } record2400_t;
 
-/* One candidate: 1 and *r filled when some phase yields an acceptable frame. */
-int oracle2400_demod_at(const uint16_t* m, size_t n, size_t j, uint32_t buffer, void* rec_out)
+#define RUN_BLOCK2400 8 /* runs of gate survivors are cut at multiples of this many positions */
+
+/* best preamble score of the window at w and its phase (the first phase of maximal P) */
+long oracle2400_preamble(const uint16_t* w, int* phi_out)
 {
-    if (n <= SPAN2400 || j >= n - SPAN2400) return 0;
-    const uint16_t* w = m + j;
-    long            best = 0;
-    int             phi_star = -1;
+    long best     = 0;
+    int  phi_star = -1;
     for (int phi = 0; phi < 5; phi++)
     {
         long p = slot_energy(w, phi, 0) + slot_energy(w, phi, 2) + slot_energy(w, phi, 7) + slot_energy(w, phi, 9) - slot_energy(w, phi, 1) -
@@ -150,6 +152,17 @@ int oracle2400_demod_at(const uint16_t* m, size_t n, size_t j, uint32_t buffer, 
             phi_star = phi;
         }
     }
+    *phi_out = phi_star;
+    return best;
+}
+
+/* One candidate: 1 and *r filled when some phase yields an acceptable frame. */
+int oracle2400_demod_at(const uint16_t* m, size_t n, size_t j, uint32_t buffer, void* rec_out)
+{
+    if (n <= SPAN2400 || j >= n - SPAN2400) return 0;
+    const uint16_t* w = m + j;
+    int             phi_star = -1;
+    const long      best = oracle2400_preamble(w, &phi_star);
     if (best <= 0) return 0;
     const long amp      = (slot_energy(w, phi_star, 0) + slot_energy(w, phi_star, 2) + slot_energy(w, phi_star, 7) + slot_energy(w, phi_star, 9)) / 24;
     const int  order[3] = {phi_star, phi_star + 1, phi_star - 1};
@@ -202,43 +215,36 @@ size_t oracle2400_expected_records(const uint8_t* iq, size_t nbytes, size_t buff
             uint32_t s  = (uint32_t)(di * di + dq * dq);
             pw[k]       = (uint16_t)(s > 32767u ? 32767u : s);
         }
-        for (size_t j = 0; j + SPAN2400 < n; j++)
+        /* Runs of gate survivors at consecutive positions, cut at multiples of RUN_BLOCK2400: a frame passes the gate at two or three
+         * neighbouring positions; only the member with the largest positive preamble score (the first such) is demodulated. */
+        for (size_t j = 0; j + SPAN2400 < n;)
         {
-            if (!oracle2400_gate(pw, n, j)) continue;
+            if (!oracle2400_gate(pw, n, j))
+            {
+                j++;
+                continue;
+            }
+            size_t end = j + 1;
+            while (end + SPAN2400 < n && (end % RUN_BLOCK2400) != 0 && oracle2400_gate(pw, n, end)) end++;
+            size_t pick = j;
+            long   top  = 0;
+            int    any  = 0;
+            for (size_t k = j; k < end; k++)
+            {
+                int        phi;
+                const long p = oracle2400_preamble(mag + k, &phi);
+                if (p > 0 && (!any || p > top)) top = p, pick = k, any = 1;
+            }
             record2400_t r;
-            if (oracle2400_demod_at(mag, n, j, (uint32_t)b, &r))
+            if (any && oracle2400_demod_at(mag, n, pick, (uint32_t)b, &r))
             {
                 if (total < cap) ((record2400_t*)out)[total] = r;
                 total++;
             }
+            j = end;
         }
     }
     free(mag);
     free(pw);
     return total;
-}
-
-/* diagnostics for tuning (not used by the tests): gate passes, and for each the best preamble score and pulse energy */
-size_t oracle2400_gate_stats(const uint8_t* iq, size_t nbytes, long* out_p, long* out_e, uint32_t* out_j, size_t cap)
-{
-    size_t n = nbytes / 2, k = 0;
-    uint16_t* mag = (uint16_t*)malloc(n * 2); uint16_t* pw = (uint16_t*)malloc(n * 2);
-    oracle1090_magnitude(iq, nbytes, mag);
-    for (size_t i = 0; i < n; i++) { int di = (int)iq[2*i]-127, dq = (int)iq[2*i+1]-127; uint32_t s = (uint32_t)(di*di+dq*dq); pw[i] = (uint16_t)(s > 32767u ? 32767u : s); }
-    for (size_t j = 0; j + SPAN2400 < n; j++)
-    {
-        if (!oracle2400_gate(pw, n, j)) continue;
-        long best = 0, e = 0; int ps = -1;
-        for (int phi = 0; phi < 5; phi++)
-        {
-            const uint16_t* w = mag + j;
-            long pe = slot_energy(w, phi, 0) + slot_energy(w, phi, 2) + slot_energy(w, phi, 7) + slot_energy(w, phi, 9);
-            long p = pe - slot_energy(w, phi, 1) - slot_energy(w, phi, 3) - slot_energy(w, phi, 4) - slot_energy(w, phi, 5) - slot_energy(w, phi, 6) - slot_energy(w, phi, 8);
-            if (ps < 0 || p > best) { best = p; ps = phi; e = pe; }
-        }
-        if (k < cap) { out_p[k] = best; out_e[k] = e; out_j[k] = (uint32_t)j; }
-        k++;
-    }
-    free(mag); free(pw);
-    return k;
 }
