@@ -362,19 +362,19 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
             const bool     in  = q < nq;
             const uint32_t pos = in ? queue[q] : 0u;
             const uint32_t sc  = in ? score[q] >> 3 : 0u;
-            bool           win = sc > 0u, run = true;
-#pragma unroll
-            for (uint32_t k = 1; k < 8; k++)
+            bool           win = sc > 0u, run = win; // an entry without a score cannot stand for its run: no need to look around it
+#pragma unroll 1
+            for (uint32_t k = 1; k < 8 && ballot(run); k++)
             { // earlier members
                 run = run && k <= (pos & 7u) && q >= k && queue[q - k] == pos - k;
-                if (run && (score[q - k] >> 3) >= sc) win = false;
+                if (run && (score[q - k] >> 3) >= sc) win = false, run = false;
             }
-            run = true;
-#pragma unroll
-            for (uint32_t k = 1; k < 8; k++)
+            run = win;
+#pragma unroll 1
+            for (uint32_t k = 1; k < 8 && ballot(run); k++)
             { // later members
                 run = run && (pos & 7u) + k < 8u && q + k < nq && queue[q + k] == pos + k;
-                if (run && (score[q + k] >> 3) > sc) win = false;
+                if (run && (score[q + k] >> 3) > sc) win = false, run = false;
             }
             const uint64_t wins = ballot(win);
             if (win) wlist[nw + (uint32_t)__builtin_popcountll(wins & ((1ull << lane) - 1ull))] = (uint16_t)q;

@@ -453,24 +453,51 @@ template <bool PHASES_GIVEN>
 __device__ __noinline__ void stage_dphi(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n, uint64_t base,
                                            int16_t* dphi_s, int lane)
 {
-    uint32_t   ph[2][8];
     const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
+    if (aligned && base + (uint64_t)kUatTile + 1 <= n)
+    { // the whole tile and the sample after it lie inside the stream (wave-uniform; every tile but a stream's last few): no guards,
+      // two phases per register, the pair shifted by one sample from v_alignbit, two wrapped differences per v_pk_sub_i16
+        uint32_t p[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+        {
+            const uint4    x    = *reinterpret_cast<const uint4*>(in + base + 8ull * (uint64_t)(lane + 64 * r));
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                if (PHASES_GIVEN) p[r][k] = w[k];
+                else
+                {
+                    const char*    b  = reinterpret_cast<const char*>(lut);
+                    const uint32_t lo = *reinterpret_cast<const uint16_t*>(b + table_offset_lo(w[k]));
+                    const uint32_t hi = *reinterpret_cast<const uint16_t*>(b + table_offset_hi(w[k]));
+                    p[r][k]           = __builtin_amdgcn_perm(hi, lo, 0x05040100u); // hi.word0 : lo.word0
+                }
+            }
+        }
+        const uint32_t after = in[base + (uint64_t)kUatTile]; // only lane 63 of round 1 uses it
+        const uint32_t after_ph = PHASES_GIVEN ? after : (uint32_t)lut[after];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+        {
+            const uint32_t wrap = r == 0 ? (uint32_t)__builtin_amdgcn_readlane((int)p[1][0], 0) : after_ph;
+            const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp((int)wrap, (int)p[r][0], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+            const uint32_t p12 = __builtin_amdgcn_alignbit(p[r][1], p[r][0], 16), p34 = __builtin_amdgcn_alignbit(p[r][2], p[r][1], 16);
+            const uint32_t p56 = __builtin_amdgcn_alignbit(p[r][3], p[r][2], 16), p78 = __builtin_amdgcn_alignbit(next, p[r][3], 16);
+            *reinterpret_cast<uint4*>(dphi_s + 8 * (lane + 64 * r)) =
+                make_uint4(pk_sub_i16(p12, p[r][0]), pk_sub_i16(p34, p[r][1]), pk_sub_i16(p56, p[r][2]), pk_sub_i16(p78, p[r][3]));
+        }
+        return;
+    }
+    uint32_t ph[2][8];
 #pragma unroll
     for (int r = 0; r < 2; r++)
     {
         const uint64_t s = base + 8ull * (uint64_t)(lane + 64 * r);
         uint32_t       raw[8];
-        if (aligned && s + 8 <= n)
-        {
-            const uint4 x = *reinterpret_cast<const uint4*>(in + s);
-            raw[0] = x.x & 0xFFFFu, raw[1] = x.x >> 16, raw[2] = x.y & 0xFFFFu, raw[3] = x.y >> 16;
-            raw[4] = x.z & 0xFFFFu, raw[5] = x.z >> 16, raw[6] = x.w & 0xFFFFu, raw[7] = x.w >> 16;
-        }
-        else
-        {
 #pragma unroll
-            for (int k = 0; k < 8; k++) raw[k] = (s + (uint64_t)k < n) ? in[s + (uint64_t)k] : 0u;
-        }
+        for (int k = 0; k < 8; k++) raw[k] = (s + (uint64_t)k < n) ? in[s + (uint64_t)k] : 0u;
 #pragma unroll
         for (int k = 0; k < 8; k++) ph[r][k] = PHASES_GIVEN ? raw[k] : (uint32_t)lut[raw[k]];
     }
