@@ -542,18 +542,29 @@ __device__ __forceinline__ uint64_t sign_window_tile(const int16_t* dphi_s, int 
 {
     return __ballot(dphi_s[off + 2 * (lane & 31) + (lane >> 5)] > 0);
 }
-// frame bits 64 g .. 64 g + 63 (g in [g0, g1)) of a frame whose bit 0 sits at tile index off0; MSB-first bytes into out[]
-__device__ __forceinline__ void slice_groups_tile(const int16_t* dphi_s, int off0, int center, int nbits, int g0, int g1, uint8_t* out, int lane)
+// frame bytes b0 .. b1 - 1 of a frame whose bit 0 sits at tile index off0, into out[]: lane l slices byte b0 + l from the eight
+// differences two samples apart -- packed in pairs, centre - d saturated (negative exactly when d > centre), the sign bits
+// gathered MSB-first by v_dot2.  (Round-1 form: 64 bits per ballot, eight lanes unpacking each ballot: 3.5 times the instructions.)
+__device__ __forceinline__ void slice_bytes_tile(const int16_t* dphi_s, int off0, int center, int b0, int b1, uint8_t* out, int lane)
 {
-    for (int g = g0; g < g1; g++)
+    typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+    for (int bb = b0; bb < b1; bb += 64)
     {
-        const int      gbase = 64 * g, bit = gbase + lane;
-        const int      d     = bit < nbits ? (int)dphi_s[off0 + 2 * bit] : 0;
-        const uint64_t bits  = __ballot(bit < nbits && d > center);
-        if (lane < 8 && gbase + 8 * lane < nbits)
+        const int byte = bb + lane;
+        if (byte < b1)
         {
-            const uint32_t byte      = (uint32_t)(bits >> (8 * lane)) & 0xFFu;
-            out[(gbase >> 3) + lane] = (uint8_t)(__builtin_bitreverse32(byte) >> 24);
+            const uint16_t* d  = reinterpret_cast<const uint16_t*>(dphi_s) + (off0 + 16 * byte);
+            const uint32_t  c2 = ((uint32_t)center & 0xFFFFu) * 0x00010001u;
+            uint32_t        acc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const uint32_t pair = (uint32_t)d[4 * k] | ((uint32_t)d[4 * k + 2] << 16);
+                uint32_t       t;
+                asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(t) : "v"(c2), "v"(pair));
+                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u, t & 0x80008000u), (v2u){(unsigned short)(128 >> (2 * k)), (unsigned short)(64 >> (2 * k))}, acc, false);
+            }
+            out[byte] = (uint8_t)(acc >> 15);
         }
     }
 }
@@ -817,7 +828,7 @@ __global__ __launch_bounds__(64, 5) void uat_demod_kernel(const uint16_t* __rest
                 if (v == 1 && skip0 && rs0 == 0) break;
                 const SyncCheck sc = check_sync_tile(dphi_s, o + v, false, lane);
                 if (!sc.ok) continue;
-                slice_groups_tile(dphi_s, o + v + 72, sc.center, nbits, 0, nbits / 64, raw[v], lane);
+                slice_bytes_tile(dphi_s, o + v + 72, sc.center, 0, nbits / 8, raw[v], lane);
                 wave_fence();
                 syndromes_wave(T, 14, 48, raw[v], 1, work[v].s, lane);
                 wave_fence();
@@ -857,7 +868,7 @@ __global__ __launch_bounds__(64, 5) void uat_demod_kernel(const uint16_t* __rest
                             int       g0 = (t * kUatTileStride - first + 127) / 128, g1 = ((t + 1) * kUatTileStride - first + 127) / 128;
                             if (t == 0) g0 = 0;
                             if (g1 > nbits / 64) g1 = nbits / 64;
-                            slice_groups_tile(dphi_s, first - t * kUatTileStride, center[v], nbits, g0, g1, raw[v], lane);
+                            slice_bytes_tile(dphi_s, first - t * kUatTileStride, center[v], 8 * g0, 8 * g1, raw[v], lane);
                         }
                     const int after = oe + 2 * (kUatUplinkSkip + 1) - t * kUatTileStride; // the window behind the frame
                     if (after >= 0 && after + 64 < kUatTileValid && after < kUatTileStride) w1 = sign_window_tile(dphi_s, after, lane);
