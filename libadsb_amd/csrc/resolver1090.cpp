@@ -114,40 +114,36 @@ void Resolver1090::set_sample_clock(int64_t t0_ns, uint32_t rate_hz)
 // InteractiveReceiveData (ADSB1090.cpp:1124-1175) on the decoded fields
 void Resolver1090::apply(const adsb_amd_decoded_t& d, int64_t t, Track& a)
 {
-    switch (d.kind)
+    // The kind of a frame does not predict (a busy sky interleaves them at random), so the three plain updates are selects, not a
+    // switch: measured 1.3 ms of 5.3 per GiB-equivalent of records in the build container went to mispredicted branches here.
+    const unsigned k       = d.kind;
+    const bool     has_alt = (k == ADSB_AMD_K_ALTITUDE) | (k == ADSB_AMD_K_POSITION);
+    a.pub.altitude         = has_alt ? d.altitude : a.pub.altitude;
+    uint64_t cs_old;
+    std::memcpy(&cs_old, a.pub.callsign, 8);
+    const uint64_t cs_new = (uint64_t)d.a | ((uint64_t)d.b << 32);
+    const uint64_t cs     = (k == ADSB_AMD_K_IDENT) ? cs_new : cs_old;
+    std::memcpy(a.pub.callsign, &cs, 8);
+    const bool vel = k == ADSB_AMD_K_VELOCITY;
+    a.pub.speed    = vel ? d.a : a.pub.speed;
+    a.pub.track    = vel ? d.b : a.pub.track;
+    if (k != ADSB_AMD_K_POSITION) return;
+    if (d.odd)
     {
-    case ADSB_AMD_K_ALTITUDE: a.pub.altitude = d.altitude; break;
-    case ADSB_AMD_K_IDENT:
-        std::memcpy(a.pub.callsign, &d.a, 4);
-        std::memcpy(a.pub.callsign + 4, &d.b, 4);
-        break;
-    case ADSB_AMD_K_POSITION:
+        a.odd_lat = d.a;
+        a.odd_lon = d.b;
+        a.odd_ns  = t;
+    }
+    else
     {
-        a.pub.altitude = d.altitude;
-        if (d.odd)
-        {
-            a.odd_lat = d.a;
-            a.odd_lon = d.b;
-            a.odd_ns  = t;
-        }
-        else
-        {
-            a.even_lat = d.a;
-            a.even_lon = d.b;
-            a.even_ns  = t;
-        }
-        int64_t whole_seconds = (a.even_ns - a.odd_ns) / kNsPerSec; // duration_cast<seconds>: toward zero
-        if (whole_seconds < 0) whole_seconds = -whole_seconds;
-        if (whole_seconds <= kCprPairSeconds)
-            cpr_global(a.even_lat, a.even_lon, a.odd_lat, a.odd_lon, a.even_ns > a.odd_ns, &a.pub.lat1e7, &a.pub.lon1e7);
-        break;
+        a.even_lat = d.a;
+        a.even_lon = d.b;
+        a.even_ns  = t;
     }
-    case ADSB_AMD_K_VELOCITY:
-        a.pub.speed = d.a;
-        a.pub.track = d.b;
-        break;
-    default: break;
-    }
+    int64_t whole_seconds = (a.even_ns - a.odd_ns) / kNsPerSec; // duration_cast<seconds>: toward zero
+    if (whole_seconds < 0) whole_seconds = -whole_seconds;
+    if (whole_seconds <= kCprPairSeconds)
+        cpr_global(a.even_lat, a.even_lon, a.odd_lat, a.odd_lon, a.even_ns > a.odd_ns, &a.pub.lat1e7, &a.pub.lon1e7);
 }
 
 // Tried and dropped (round 2): splitting a large call into a sequential gating pass on this thread, the per-aircraft updates on
