@@ -288,6 +288,10 @@ int adsb_amd_uat_process_iq(adsb_amd_uat_t* u, const void* iq, uint64_t nsamples
  * valid until it is collected.  Results are identical to adsb_amd_uat_process_iq call by call. */
 int adsb_amd_uat_submit_iq(adsb_amd_uat_t* u, const void* iq_device, uint64_t nsamples, uint64_t offset);
 int adsb_amd_uat_collect(adsb_amd_uat_t* u, adsb_amd_uat_frame_fn cb, void* user, int64_t* consumed);
+/* Parity helpers for the CPU tests: the scan loop's filter for the 17 steps after a jump (bit t set = step t can still fire, given a
+ * register's 18 old bits and the bits that enter it, both in stream order), and the 18-bit check words in the same order. */
+uint32_t adsb_amd_uat_possible_steps(uint32_t old_register, uint32_t fresh_bits);
+uint32_t adsb_amd_uat_check_word(int uplink);
 /* device time of the last process call (sign+match kernels, demod kernel) and running totals of 18-bit matches and of
  * positions the host had to ask the device about on top of those */
 int adsb_amd_uat_timing(const adsb_amd_uat_t* u, float* scan_ms, float* demod_ms, uint64_t* candidates, uint64_t* extra_lookups);

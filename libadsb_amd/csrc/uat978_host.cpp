@@ -770,6 +770,10 @@ extern "C" int adsb_amd_uat_process_iq(adsb_amd_uat_t* u, const void* iq, uint64
     else if (reinterpret_cast<uintptr_t>(iq) & 15u) return u->fail(ADSB_AMD_EINVAL, "device IQ pointer must be 16-byte aligned");
     return u->process(dev, nsamples, false, offset, cb, user, consumed);
 }
+// parity helper (CPU tests): the step filter of the scan loop's post-jump window, and the two check words in stream order
+extern "C" uint32_t adsb_amd_uat_possible_steps(uint32_t oldw, uint32_t fresh) { return possible_steps(oldw & kCheckMask, fresh); }
+extern "C" uint32_t adsb_amd_uat_check_word(int uplink) { return kCheckT[uplink ? 1 : 0]; }
+
 extern "C" int adsb_amd_uat_submit_iq(adsb_amd_uat_t* u, const void* iq_device, uint64_t nsamples, uint64_t offset)
 {
     if (!u || (!iq_device && nsamples)) return ADSB_AMD_EINVAL;

@@ -266,3 +266,41 @@ def test_transport_ring_replay_and_push(native_libs, tmp_path):
     with pytest.raises(A.AdsbAmdError):
         t.push(np.zeros(BB + 2, dtype=np.uint8))
     t.close()
+
+
+def test_uat_post_jump_step_filter_never_hides_a_step_that_fires(native_libs):
+    """uat978_host.cpp: after a jump the scan loop's registers hold 18 - t old bits and t new ones at step t; the loop first asks a
+    two-byte filter which steps can fire at all.  A step that fires (register == a check word) must survive the filter: every
+    placement of both check words at every step, with random bits around them, and random histories against the plain comparison."""
+    import ctypes as C
+    L = A.lib()
+    L.adsb_amd_uat_possible_steps.restype = C.c_uint32
+    L.adsb_amd_uat_possible_steps.argtypes = [C.c_uint32, C.c_uint32]
+    L.adsb_amd_uat_check_word.restype = C.c_uint32
+    L.adsb_amd_uat_check_word.argtypes = [C.c_int]
+    words = [L.adsb_amd_uat_check_word(0), L.adsb_amd_uat_check_word(1)]
+    assert words[0] ^ words[1] == 0x3FFFF  # complements on their 18 bits
+    rng = np.random.default_rng(978)
+    mask = (1 << 18) - 1
+
+    def fires(x, t):
+        return ((x >> t) & mask) in words
+
+    for w in words:
+        for t in range(1, 18):
+            for _ in range(200):
+                x = int(rng.integers(0, 1 << 50))
+                x = (x & ~(mask << t)) | (w << t)  # the check word sits at step t
+                got = L.adsb_amd_uat_possible_steps(x & mask, (x >> 18) & 0xFFFFFFFF)
+                assert got & (1 << t), (hex(x), t)
+    kept = total = 0
+    for _ in range(20000):
+        x = int(rng.integers(0, 1 << 50))
+        got = L.adsb_amd_uat_possible_steps(x & mask, (x >> 18) & 0xFFFFFFFF)
+        assert got & ~0x3FFFE == 0
+        for t in range(1, 18):
+            total += 1
+            kept += (got >> t) & 1
+            if fires(x, t):
+                assert got & (1 << t)
+    assert kept < total * 0.02  # random histories keep about 2 of 256 steps
