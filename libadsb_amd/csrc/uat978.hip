@@ -11,11 +11,15 @@
 //                          wrapped 16-bit differences, sign bits, both 18-bit check words -- bound by the HBM read (2 B/sample)
 //   uat_sign_kernel +      the same two steps for a buffer of *phases* (the process_buffer seam and the 65 536-entry staging
 //   uat_match_kernel       rounds of HandleData; small inputs)
-//   uat_demod_kernel       one wave per match (the host may also ask for further sample indices, see uat978_host.cpp): the
-//                          36-bit sync re-check against the data-derived centre for the match and for the next sample (the
-//                          reference tries both), the frame sliced at that centre, and its Reed-Solomon decode with the whole
-//                          wave on one code word (rs978.h: Berlekamp-Massey, Chien, Forney with libfec's conventions)
-//   uat_order_*            counting sort of the matches by stream position, on the device
+//   uat_demod_kernel       one wave per match (the host may also ask for further sample indices, see uat978_host.cpp): one coalesced
+//                          burst stages the phase differences of the match's samples in LDS (ten tiles for an uplink frame), then
+//                          the 36-bit sync re-check against the data-derived centre for the match and, when that one needed
+//                          corrections, for the next sample (the reference tries both and keeps the better), the frame sliced a
+//                          byte per lane at that centre, its syndromes with the wave across the symbols and its Reed-Solomon
+//                          decode with the whole wave on one code word (rs978.h: Berlekamp-Massey, Chien, Forney with libfec's
+//                          conventions); the choice between the two alignments is made here, a record is 64 bytes
+//   uat_order_*            counting sort of the matches by stream position, on the device; also lists the uplink matches, which the
+//                          demodulation takes first
 // Only the order-dependent scan-loop rules (which match the loop reaches, frame choice, skip-ahead) run on the host.
 #include <hip/hip_runtime.h>
 
