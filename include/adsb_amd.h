@@ -196,7 +196,8 @@ long adsb_amd_resolver_feed_decoded(adsb_amd_resolver_t* r, const adsb_amd_recor
                                     size_t samples_per_buffer, size_t nbuffers, adsb_amd_on_changed_fn cb, void* user);
 size_t adsb_amd_resolver_aircraft_count(const adsb_amd_resolver_t* r);
 /* Parity helpers (host only): CprNlFunction (ADSB1090.cpp:993-1055) and the global airborne decode (:1079-1121) as the resolver
- * computes them; adsb_amd_cpr_global returns 0 when the two latitudes fall into different zones (state untouched). */
+ * computes them; the four arguments of adsb_amd_cpr_global are the raw 17-bit CPR values (whole numbers; a fraction is dropped); it returns 0
+ * when the two latitudes fall into different zones (state untouched). */
 int adsb_amd_cpr_nl(double lat);
 int adsb_amd_cpr_global(double even_lat, double even_lon, double odd_lat, double odd_lon, int use_even, int32_t* lat1e7, int32_t* lon1e7);
 /* An adsb_amd_on_changed_fn that only counts: *(uint64_t*)user += 1 per call (IListener::OnChanged stand-in for rate runs). */

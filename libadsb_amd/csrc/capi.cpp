@@ -753,7 +753,7 @@ extern "C" long adsb_amd_resolver_feed_decoded(adsb_amd_resolver_t* r, const ads
 extern "C" int adsb_amd_cpr_nl(double lat) { return adsb_amd::cpr_nl(lat); }
 extern "C" int adsb_amd_cpr_global(double even_lat, double even_lon, double odd_lat, double odd_lon, int use_even, int32_t* lat1e7, int32_t* lon1e7)
 {
-    return adsb_amd::cpr_global(even_lat, even_lon, odd_lat, odd_lon, use_even != 0, lat1e7, lon1e7) ? 1 : 0;
+    return adsb_amd::cpr_global((int32_t)even_lat, (int32_t)even_lon, (int32_t)odd_lat, (int32_t)odd_lon, use_even != 0, lat1e7, lon1e7) ? 1 : 0; // raw 17-bit values
 }
 extern "C" void adsb_amd_decode_record_host(const adsb_amd_record_t* record, adsb_amd_decoded_t* out)
 {

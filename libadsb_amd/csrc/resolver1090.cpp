@@ -17,42 +17,63 @@ constexpr int64_t kCprPairSeconds  = 10;             // :1161
 } // namespace
 
 // Number of longitude zones, transition latitudes of 1090-WP-9-14 (the table the reference carries at :993-1055).
+namespace
+{
+constexpr double kNlEdge[58] = {
+    10.47047130, 14.82817437, 18.18626357, 21.02939493, 23.54504487, 25.82924707, 27.93898710, 29.91135686, 31.77209708,
+    33.53993436, 35.22899598, 36.85025108, 38.41241892, 39.92256684, 41.38651832, 42.80914012, 44.19454951, 45.54626723,
+    46.86733252, 48.16039128, 49.42776439, 50.67150166, 51.89342469, 53.09516153, 54.27817472, 55.44378444, 56.59318756,
+    57.72747354, 58.84763776, 59.95459277, 61.04917774, 62.13216659, 63.20427479, 64.26616523, 65.31845310, 66.36171008,
+    67.39646774, 68.42322022, 69.44242631, 70.45451075, 71.45986473, 72.45884545, 73.45177442, 74.43893416, 75.42056257,
+    76.39684391, 77.36789461, 78.33374083, 79.29428225, 80.24923213, 81.19801349, 82.13956981, 83.07199445, 83.99173563,
+    84.89166191, 85.75541621, 86.53536998, 87.00000000};
+// at[q] = number of edges <= q/4 degrees.  Neighbouring edges are at least 0.46 degrees apart, so a quarter degree holds at most
+// one: one table look-up and one comparison, no data-dependent branch (the latitudes of a busy sky do not predict).  Built at
+// compile time: a function-local static would cost a guard check per call.
+struct NlBelow
+{
+    uint8_t at[4 * 91 + 4];
+    double  e[60];
+};
+constexpr NlBelow make_nl_below()
+{
+    NlBelow b{};
+    for (int k = 0; k < 60; k++) b.e[k] = k < 58 ? kNlEdge[k] : 1e300;
+    for (int q = 0; q < 4 * 91 + 4; q++)
+    {
+        int k = 0;
+        while (k < 58 && kNlEdge[k] <= q * 0.25) k++;
+        b.at[q] = (uint8_t)k;
+    }
+    return b;
+}
+constexpr NlBelow kNlBelow = make_nl_below();
+// 360.0 / ni for ni = 1 .. 59: the quotients the reference's expression forms
+struct Dlon
+{
+    double v[60];
+};
+constexpr Dlon make_dlon()
+{
+    Dlon d{};
+    d.v[0] = 0;
+    for (int i = 1; i < 60; i++) d.v[i] = 360.0 / i;
+    return d;
+}
+constexpr Dlon kDlon = make_dlon();
+} // namespace
+
 int cpr_nl(double lat)
 {
-    static const double edge[58] = {
-        10.47047130, 14.82817437, 18.18626357, 21.02939493, 23.54504487, 25.82924707, 27.93898710, 29.91135686, 31.77209708,
-        33.53993436, 35.22899598, 36.85025108, 38.41241892, 39.92256684, 41.38651832, 42.80914012, 44.19454951, 45.54626723,
-        46.86733252, 48.16039128, 49.42776439, 50.67150166, 51.89342469, 53.09516153, 54.27817472, 55.44378444, 56.59318756,
-        57.72747354, 58.84763776, 59.95459277, 61.04917774, 62.13216659, 63.20427479, 64.26616523, 65.31845310, 66.36171008,
-        67.39646774, 68.42322022, 69.44242631, 70.45451075, 71.45986473, 72.45884545, 73.45177442, 74.43893416, 75.42056257,
-        76.39684391, 77.36789461, 78.33374083, 79.29428225, 80.24923213, 81.19801349, 82.13956981, 83.07199445, 83.99173563,
-        84.89166191, 85.75541621, 86.53536998, 87.00000000};
-    // below[q] = number of edges <= q/4 degrees.  Neighbouring edges are at least 0.46 degrees apart, so a quarter degree holds
-    // at most one: one table look-up and one comparison, no data-dependent branch (the latitudes of a busy sky do not predict)
-    static const struct Below
-    {
-        uint8_t at[4 * 91 + 4];
-        double  e[60];
-        Below()
-        {
-            for (int k = 0; k < 60; k++) e[k] = k < 58 ? edge[k] : 1e300;
-            for (int q = 0; q < 4 * 91 + 4; q++)
-            {
-                int k = 0;
-                while (k < 58 && edge[k] <= q * 0.25) k++;
-                at[q] = (uint8_t)k;
-            }
-        }
-    } below;
     const double a = lat < 0 ? -lat : lat;
     if (!(a >= 0.0 && a < 91.0))
     { // NaN and out-of-range latitudes: the plain scan
         int k = 0;
-        while (k < 58 && !(a < edge[k])) k++;
+        while (k < 58 && !(a < kNlEdge[k])) k++;
         return 59 - k;
     }
-    int k = below.at[(int)(a * 4.0)];
-    k += !(a < below.e[k]);
+    int k = kNlBelow.at[(int)(a * 4.0)];
+    k += !(a < kNlBelow.e[k]);
     return 59 - k;
 }
 
@@ -71,31 +92,24 @@ int wrap_small(int a, int b)
 }
 } // namespace
 
-bool cpr_global(double lat0, double lon0, double lat1, double lon1, bool use_even, int32_t* lat1e7, int32_t* lon1e7)
+bool cpr_global(int32_t lat0, int32_t lon0, int32_t lat1, int32_t lon1, bool use_even, int32_t* lat1e7, int32_t* lon1e7)
 {
-    // 360.0 / ni for ni = 1 .. 59: the same quotients the expression below would form, computed once
-    static const struct Dlon
-    {
-        double v[60];
-        Dlon()
-        {
-            v[0] = 0;
-            for (int i = 1; i < 60; i++) v[i] = 360.0 / i;
-        }
-    } dlon;
+    // The reference's expressions (:1079-1121) are in double; with whole-number operands below 2^17 every product, difference and
+    // division by 131072 in them is exact, so floor(x / 131072 + 0.5) is the arithmetic shift (x + 65536) >> 17 -- the two zone
+    // indices are formed in integers, everything that is scaled by 360/60, 360/59 or 360/ni stays in double as written there.
     const double d0 = 360.0 / 60, d1 = 360.0 / 59;
-    const int    j  = static_cast<int>(std::floor(((59 * lat0 - 60 * lat1) / 131072) + 0.5));
-    double       r0 = d0 * (wrap(j, 60) + lat0 / 131072);
-    double       r1 = d1 * (wrap(j, 59) + lat1 / 131072);
+    const int    j  = (int)((59 * (int64_t)lat0 - 60 * (int64_t)lat1 + 65536) >> 17);
+    double       r0 = d0 * (wrap_small(j, 60) + (double)lat0 / 131072);
+    double       r1 = d1 * (wrap_small(j, 59) + (double)lat1 / 131072);
     if (r0 >= 270) r0 -= 360;
     if (r1 >= 270) r1 -= 360;
     const int nl0 = cpr_nl(r0), nl1 = cpr_nl(r1);
     if (nl0 != nl1) return false;
     const int    nl  = nl0;
     const int    ni  = use_even ? (nl < 1 ? 1 : nl) : (nl - 1 < 1 ? 1 : nl - 1); // N(lat, 0) / N(lat, 1)
-    const int    m   = static_cast<int>(std::floor((((lon0 * (nl - 1)) - (lon1 * nl)) / 131072) + 0.5));
+    const int    m   = (int)(((int64_t)lon0 * (nl - 1) - (int64_t)lon1 * nl + 65536) >> 17);
     const double lon = use_even ? lon0 : lon1, rlat = use_even ? r0 : r1;
-    double lon_out   = dlon.v[ni] * (wrap_small(m, ni) + lon / 131072) * 10000000;
+    double lon_out   = kDlon.v[ni] * (wrap_small(m, ni) + lon / 131072) * 10000000;
     double lat_out   = rlat * 10000000;
     if (lon_out > 180.0 * 10000000) lon_out -= 3600000000.0;
     *lat1e7 = static_cast<int32_t>(lat_out);
@@ -130,14 +144,14 @@ void Resolver1090::apply(const adsb_amd_decoded_t& d, int64_t t, Track& a)
     if (k != ADSB_AMD_K_POSITION) return;
     if (d.odd)
     {
-        a.odd_lat = d.a;
-        a.odd_lon = d.b;
+        a.odd_lat = (int32_t)d.a;
+        a.odd_lon = (int32_t)d.b;
         a.odd_ns  = t;
     }
     else
     {
-        a.even_lat = d.a;
-        a.even_lon = d.b;
+        a.even_lat = (int32_t)d.a;
+        a.even_lon = (int32_t)d.b;
         a.even_ns  = t;
     }
     int64_t whole_seconds = (a.even_ns - a.odd_ns) / kNsPerSec; // duration_cast<seconds>: toward zero

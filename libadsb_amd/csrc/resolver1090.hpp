@@ -21,7 +21,7 @@ namespace adsb_amd
 
 int cpr_nl(double lat);
 // Global airborne CPR from an even and an odd frame; false when the two latitudes fall in different NL zones.
-bool cpr_global(double even_lat, double even_lon, double odd_lat, double odd_lon, bool use_even, int32_t* lat1e7, int32_t* lon1e7);
+bool cpr_global(int32_t even_lat, int32_t even_lon, int32_t odd_lat, int32_t odd_lon, bool use_even, int32_t* lat1e7, int32_t* lon1e7); // raw 17-bit CPR values
 
 class Resolver1090
 {
@@ -40,7 +40,7 @@ class Resolver1090
         int64_t             seen_ns = 0; // last clean DF11/17 (the reference's ICAO cache entry, :195-207); valid when `seen`
         bool                seen    = false;
         adsb_amd_aircraft_t pub{};
-        double              even_lat = 0, even_lon = 0, odd_lat = 0, odd_lon = 0;
+        int32_t             even_lat = 0, even_lon = 0, odd_lat = 0, odd_lon = 0; // raw 17-bit CPR values
         int64_t             even_ns = 0, odd_ns = 0; // 0 = never (the reference's default time_point)
     };
     // The reference keeps two unordered_maps keyed by the 24-bit address (ICAO cache :195-207, TrafficManager's aircraft,

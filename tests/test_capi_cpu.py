@@ -150,10 +150,13 @@ def test_cpr_zone_lookup_and_global_decode_equal_the_oracle(native_libs):
     a, b = C.c_int32(), C.c_int32()
     c, d = C.c_int32(), C.c_int32()
     n_ok = 0
-    for _ in range(20000):
+    for trial in range(40000):
         lat0, lon0 = int(rng.integers(0, 131072)), int(rng.integers(0, 131072))
-        lat1 = (lat0 + int(rng.integers(-3000, 3000))) % 131072
-        lon1 = (lon0 + int(rng.integers(-3000, 3000))) % 131072
+        if trial < 20000:  # an aircraft's consecutive frames
+            lat1 = (lat0 + int(rng.integers(-3000, 3000))) % 131072
+            lon1 = (lon0 + int(rng.integers(-3000, 3000))) % 131072
+        else:  # anything (the zone indices are formed in integers in the product: every sign and wrap of j and m)
+            lat1, lon1 = int(rng.integers(0, 131072)), int(rng.integers(0, 131072))
         for use_even in (0, 1):
             r0 = L.adsb_amd_cpr_global(lat0, lon0, lat1, lon1, use_even, C.byref(a), C.byref(b))
             r1 = OL.oracle1090_decode_cpr(lat0, lon0, lat1, lon1, use_even, C.byref(c), C.byref(d))
