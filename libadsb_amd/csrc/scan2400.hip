@@ -198,7 +198,6 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     const WorkRange wr    = work_range(a);
     uint32_t        chunk = wr.first + wr.slot;
     if (chunk >= wr.end) return;
-    stagger_wave();
     uint32_t  next  = chunk + wr.nslot;
     uint32_t  ahead = grab_chunk(a, wr, lane);
     ChunkGeom g     = chunk_geom(a, chunk / a.chunks_per_buf, chunk % a.chunks_per_buf, kSpan24);
@@ -208,6 +207,7 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     for (;;)
     {
     // ---------------- window -> s, the two halves of the chunk interleaved (rows j and j + 4; j = 4: row 4 again beside the halo row)
+    __builtin_amdgcn_s_setprio(0);
     wave_lds_fence(); // readers of the previous chunk are done
 #pragma unroll
     for (int jr = 0; jr <= kRows / 2; jr++)
@@ -281,6 +281,9 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
         else surv32[b >> 1] = acc;
     }
     uint64_t surv = (uint64_t)surv32[0] | ((uint64_t)surv32[1] << 32);
+    // the rest of the chunk is short dependent chains: raised priority lets them through the vector-dense phases of the other waves (see
+    // scan1090_kernel; 0.631 -> 0.621 ms per GiB here)
+    __builtin_amdgcn_s_setprio(1);
     if (npos < (uint32_t)kChunk)
     {
 #pragma unroll

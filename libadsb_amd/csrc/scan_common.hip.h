@@ -352,15 +352,6 @@ __device__ __forceinline__ WorkRange work_range(const ScanArgs& a)
     w.end               = (w.first + per < a.total_chunks) ? w.first + per : a.total_chunks;
     return w;
 }
-// The waves that share a SIMD run the same periodic program (memory phase, VALU-bound gates, latency-bound demodulation);
-// started together they stay in lockstep and the phases never overlap.  Offsetting each wave by its hardware slot
-// (HW_ID.wave_id, bits 3:0) spreads them over the period so one wave's loads and dependency chains hide under another's
-// arithmetic.  Purely a scheduling hint: results do not depend on it.
-__device__ __forceinline__ void stagger_wave()
-{
-    const uint32_t wslot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;
-    for (uint32_t k = 0; k < wslot; k++) __builtin_amdgcn_s_sleep(127);
-}
 // Work distribution inside a range: the first two chunks of a wave are fixed (slot, slot + nslot), every later one comes from
 // the range's counter.  Chunks differ in cost (candidates to demodulate), and with a fixed stride the slowest of 4096 waves
 // sets the kernel time; the counter is read two chunks ahead, so its latency never shows.  (Every counter on its own 128-byte

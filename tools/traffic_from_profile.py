@@ -29,23 +29,27 @@ def means(path, kernel):
     return out
 
 
-def first_existing(*names):
+def first_with_counters(kernel, *names):
+    """the first of the summaries that exists and holds FETCH_SIZE and WRITE_SIZE for the kernel (a later round may have profiled a
+    workload for time only)"""
     for n in names:
         p = os.path.join(PROF, n)
         if os.path.exists(p):
-            return p
+            m = means(p, kernel)
+            if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+                return p
     return None
 
 
 res = {}
-p = first_existing("r02_final_rocprof_summary.txt", "r01_final_rocprof_summary.txt")
+p = first_with_counters("scan1090", "r02_final_rocprof_summary.txt", "r01_final_rocprof_summary.txt")
 if p:
     m = means(p, "scan1090")
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         res["1073741824"] = {"traffic_bytes": int(round((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024)), "FETCH_SIZE_KB": m["FETCH_SIZE"], "WRITE_SIZE_KB": m["WRITE_SIZE"],
                              "kernel": "scan1090_kernel", "source": os.path.relpath(p, ROOT),
                              "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on the 1 GiB bench workload; FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads)"}
-p = first_existing("r02_uat978_rocprof_summary.txt", "r01_uat978_rocprof_summary.txt")
+p = first_with_counters("uat_scan_iq", "r02_uat978_rocprof_summary.txt", "r01_uat978_rocprof_summary.txt")
 if p:
     m = means(p, "uat_scan_iq")
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
