@@ -38,7 +38,9 @@ thread_local std::string g_create_error;
 struct Slot
 {
     uint32_t*          counts   = nullptr; // per chunk
-    uint32_t*          block_sums = nullptr; // one per 256 chunks
+    uint32_t*          block_sums = nullptr; // two arrays of one padded entry per 256 chunks: the scan adds into one, the ordering pass zeroes the other
+    size_t             sums_words = 0;       // words per array
+    int                sums_phase = 0;       // which array the next scan uses
     adsb_amd_record_t* regions  = nullptr; // total_chunks * cap
     adsb_amd_record_t* dense    = nullptr;
     adsb_amd_decoded_t* decoded = nullptr; // parallel to dense
@@ -114,7 +116,10 @@ int ensure_slot(adsb_amd_ctx* c, Slot& s, size_t chunks, size_t cap)
     free_slot(s);
     size_t nch = chunks ? chunks : 1;
     HIP_TRY(c, hipMalloc(&s.counts, nch * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc(&s.block_sums, ((nch + 255) / 256) * sizeof(uint32_t)));
+    s.sums_words = ((nch + kOrderChunks - 1) / kOrderChunks) * kSumStride;
+    s.sums_phase = 0;
+    HIP_TRY(c, hipMalloc(&s.block_sums, 2 * s.sums_words * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemset(s.block_sums, 0, 2 * s.sums_words * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc(&s.regions, nch * cap * sizeof(adsb_amd_record_t)));
     HIP_TRY(c, hipMalloc(&s.dense, nch * cap * sizeof(adsb_amd_record_t)));
     HIP_TRY(c, hipMalloc(&s.decoded, nch * cap * sizeof(adsb_amd_decoded_t)));
@@ -170,6 +175,9 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     s.args.chunk_counts  = s.counts;
     s.args.cap           = (uint32_t)s.cap_per_chunk;
     s.args.work_counters = s.work_d;
+    s.args.block_sums    = s.block_sums + (size_t)s.sums_phase * s.sums_words;
+    uint32_t* next_sums  = s.block_sums + (size_t)(s.sums_phase ^ 1) * s.sums_words;
+    if (s.args.total_chunks) s.sums_phase ^= 1; // an empty input launches nothing: the arrays keep their roles
     // Everything on the caller's stream.  (Running the ordering pass on a second stream beside the next scan was measured
     // slower, twice: with the fixed-stride scan its workgroups delayed persistent waves and the scan grew a tail; with
     // the work counters, and even with one wave slot per CU left free, the step went from 0.31 to 0.50 ms -- the small
@@ -179,7 +187,7 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     if (c->mode == ADSB_AMD_MODE_2400) HIP_TRY(c, launch_scan2400(s.args, s.total_d, s.stream));
     else HIP_TRY(c, launch_scan1090(s.args, s.total_d, s.stream));
     HIP_TRY(c, hipEventRecord(s.ev_scan1, s.stream));
-    HIP_TRY(c, launch_order1090(s.args, s.dense, s.decoded, s.block_sums, s.total_d, s.stream));
+    HIP_TRY(c, launch_order1090(s.args, s.dense, s.decoded, next_sums, (uint32_t)(s.sums_words / kSumStride), s.total_d, s.stream));
     HIP_TRY(c, hipMemcpyAsync(s.total_h, s.total_d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(c, hipEventRecord(s.ev_done, s.stream));
     return ADSB_AMD_OK;
@@ -245,7 +253,8 @@ extern "C" int adsb_amd_create_mode(adsb_amd_ctx_t** out, int device, int mode)
     if ((e = hipMemcpy(c->crc_tab, tab, sizeof(tab), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(crc)", e);
     for (Slot& s : c->slot)
     {
-        if ((e = hipMalloc(&s.total_d, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(total)", e);
+        if ((e = hipMalloc(&s.total_d, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(total)", e);
+        if ((e = hipMemset(s.total_d, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(total)", e);
         if ((e = hipMalloc(&s.work_d, kWorkCounters * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(work)", e);
         if ((e = hipMemset(s.work_d, 0, kWorkCounters * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(work)", e);
         if ((e = hipHostMalloc(&s.total_h, 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(total)", e);

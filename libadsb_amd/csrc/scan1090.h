@@ -47,7 +47,11 @@ struct ScanArgs
     uint32_t*          work_counters; // kSubRanges per XCD, counter c at [32 * c] (own cache line each), zero when the scan starts; the ordering pass zeroes them again
     uint32_t           nxcd;          // XCDs of the device (hipDeviceAttributeNumberOfXccs; 8 on MI355X), <= kMaxXcd
     uint32_t           ncu;           // compute units of the device (256 on MI355X)
+    uint32_t*          block_sums;    // one padded entry (kSumStride words) per kOrderChunks chunks, zero when the scan starts: [0] += records of a
+                                      // finished chunk (clamped to cap), [1] |= 1 when a chunk found more than cap
 };
+constexpr uint32_t kOrderChunks = 256; // chunks per entry of block_sums = per workgroup of the ordering pass
+constexpr uint32_t kSumStride   = 32;  // words between entries: an entry per 128-byte line (one atomic per chunk lands on it)
 
 constexpr uint32_t kSubRanges   = 4;  // work counters per XCD
 constexpr uint32_t kMaxXcd      = 16;
@@ -62,11 +66,12 @@ inline uint32_t chunks_per_buffer(uint32_t buf_samples)
 
 // Demodulation kernel (fills the per-chunk record regions and counts; zeroes `total_and_overflow`).
 hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream);
-// Ordering pass: per-block record sums, then the sorted gather into `dense`.  `total_and_overflow` is a device
-// uint32_t[2]: {number of records in dense, overflow flag}; `block_sums` holds one uint32_t per 256 chunks.  It only
-// touches records, so it may run on another stream beside the next scan.
-hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, adsb_amd_decoded_t* decoded, uint32_t* block_sums, uint32_t* total_and_overflow,
-                            hipStream_t stream);
+// Ordering pass: the sorted gather into `dense` (+ field decode).  `total_and_overflow` is a device uint32_t[2]: {number of
+// records in dense, overflow flag}.  a.block_sums holds what the scan accumulated; `next_block_sums` (`next_entries` padded entries, the
+// slot's whole second array) is zeroed for the next scan of this slot, and so are the work counters.  (Letting the pass write the two words into page-locked host memory
+// itself, instead of the 8-byte copy that follows it in the stream, was measured 40 us per step slower.)
+hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, adsb_amd_decoded_t* decoded, uint32_t* next_block_sums,
+                            uint32_t next_entries, uint32_t* total_and_overflow, hipStream_t stream);
 // the field decoder of the ordering pass over an arbitrary device record array (parity helper)
 hipError_t launch_decode1090(const adsb_amd_record_t* rec, adsb_amd_decoded_t* out, size_t n, hipStream_t stream);
 

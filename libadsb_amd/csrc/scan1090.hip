@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
             }
             wave_lds_fence();
         }
-        if (lane == 0) a.chunk_counts[me] = e.count;
+        if (lane == 0) publish_count(a, me, e.count);
 
         if (next >= end) break;
         chunk = next;
@@ -606,42 +606,31 @@ __device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t* wa
     return x + basev;
 }
 
-// block_sums[b] = number of records of chunks [256 b, 256 (b+1)), each chunk clamped to its region size
-__global__ __launch_bounds__(256) void block_sums_kernel(const uint32_t* __restrict__ counts, uint32_t* __restrict__ block_sums,
-                                                         uint32_t nchunks, uint32_t cap, uint32_t* __restrict__ total_overflow,
-                                                         uint32_t* __restrict__ work_counters)
-{
-    __shared__ uint32_t wave_tot[4];
-    if (blockIdx.x == 0 && threadIdx.x < kWorkCounters) work_counters[threadIdx.x * 32u] = 0; // the scan before this pass is done with them; ready for the next
-    const uint32_t      c = blockIdx.x * kOrderBlock + threadIdx.x;
-    uint32_t            v = (c < nchunks) ? counts[c] : 0u;
-    if (v > cap)
-    {
-        v = cap;
-        atomicOr(&total_overflow[1], 1u);
-    }
-    uint32_t tot;
-    (void)block_incl_scan_256(v, wave_tot, &tot);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
-
 // reverse the bit order inside each byte: message bit n (n = 8k + b, b = 0 first/MSB) -> bit 7-b of byte k
 __device__ __forceinline__ uint32_t msg_bytes(uint32_t bits) { return __builtin_bswap32(__builtin_bitreverse32(bits)); }
 
 // One workgroup per 256 chunks, one thread per chunk: position of the chunk's records in the dense array = records of all
-// earlier blocks (summed here from block_sums) + exclusive prefix inside the block; then the thread copies its chunk's
+// earlier blocks (summed here from block_sums, which the scan kernel accumulated chunk by chunk: a separate summing kernel cost
+// 4 us and a launch gap per step) + exclusive prefix inside the block; then the thread copies its chunk's
 // few records in (offset, pass) order, turning each raw record into the public adsb_amd_record_t (repair flip, byte
 // order, address).
 __global__ __launch_bounds__(256) void gather_sorted_kernel(const adsb_amd_record_t* __restrict__ chunk_records,
                                                             const uint32_t* __restrict__ counts, const uint32_t* __restrict__ block_sums,
                                                             uint32_t nchunks, uint32_t nblocks, uint32_t cap, uint32_t chunks_per_buf,
                                                             adsb_amd_record_t* __restrict__ dense, adsb_amd_decoded_t* __restrict__ decoded,
-                                                            uint32_t* __restrict__ total_overflow)
+                                                            uint32_t* __restrict__ total_overflow, uint32_t* __restrict__ next_block_sums,
+                                                            uint32_t next_entries, uint32_t* __restrict__ work_counters)
 {
     __shared__ uint32_t wave_tot[4];
+    // housekeeping for the next scan of this slot: its block sums (the other of two arrays, all of it: the next input may be larger
+    // than this one) and the work counters start from zero
+    for (uint32_t k = blockIdx.x * kOrderBlock + threadIdx.x; k < 2u * next_entries; k += nblocks * kOrderBlock)
+        next_block_sums[(k >> 1) * kSumStride + (k & 1u)] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < kWorkCounters) work_counters[threadIdx.x * 32u] = 0;
+    if (threadIdx.x == 0 && block_sums[blockIdx.x * kSumStride + 1]) atomicOr(&total_overflow[1], 1u); // some chunk of this block overflowed its region
     // records in earlier blocks
     uint32_t before = 0;
-    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kOrderBlock) before += block_sums[b];
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kOrderBlock) before += block_sums[b * kSumStride];
     uint32_t base;
     (void)block_incl_scan_256(before, wave_tot, &base);
 
@@ -764,15 +753,14 @@ hipError_t launch_decode1090(const adsb_amd_record_t* rec, adsb_amd_decoded_t* o
     return hipGetLastError();
 }
 
-hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, adsb_amd_decoded_t* decoded, uint32_t* block_sums, uint32_t* total_and_overflow,
-                            hipStream_t stream)
+hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, adsb_amd_decoded_t* decoded, uint32_t* next_block_sums,
+                            uint32_t next_entries, uint32_t* total_and_overflow, hipStream_t stream)
 {
     if (a.total_chunks == 0) return hipSuccess;
+    static_assert(kOrderBlock == kOrderChunks, "one block-sum entry per workgroup of the ordering pass");
     const uint32_t nblocks = (a.total_chunks + kOrderBlock - 1u) / kOrderBlock;
-    hipLaunchKernelGGL(block_sums_kernel, dim3(nblocks), dim3(kOrderBlock), 0, stream, a.chunk_counts, block_sums, a.total_chunks, a.cap,
-                       total_and_overflow, a.work_counters);
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderBlock), 0, stream, a.chunk_records, a.chunk_counts, block_sums, a.total_chunks,
-                       nblocks, a.cap, a.chunks_per_buf, dense, decoded, total_and_overflow);
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderBlock), 0, stream, a.chunk_records, a.chunk_counts, a.block_sums,
+                       a.total_chunks, nblocks, a.cap, a.chunks_per_buf, dense, decoded, total_and_overflow, next_block_sums, next_entries, a.work_counters);
     return hipGetLastError();
 }
 

@@ -327,6 +327,17 @@ __device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWin
     if (lane == 0 && g.g0 > 0) r.front = *reinterpret_cast<const uint16_t*>(g.buf + 2ull * (g.g0 - 1));
 }
 
+// A finished chunk: its record count for the ordering pass, and the count (clamped to the region size) added to the sum of its group
+// of kOrderChunks chunks -- the ordering pass starts from finished sums instead of running a summing kernel first.  The atomics need
+// no reply; each sum sits on its own cache line (256 additions per line over the whole scan).
+__device__ __forceinline__ void publish_count(const ScanArgs& a, uint32_t chunk, uint32_t count)
+{
+    a.chunk_counts[chunk] = count;
+    uint32_t* sum         = a.block_sums + (chunk / kOrderChunks) * kSumStride;
+    if (count) atomicAdd(sum, count < a.cap ? count : a.cap);
+    if (count > a.cap) atomicOr(sum + 1, 1u);
+}
+
 // XCD-aware chunk order: workgroups b and b + nxcd share an XCD (round-robin dispatch), so give every XCD one contiguous range
 // of chunks and let its workgroups walk that range together -> halo re-reads hit its L2.  Each XCD range is cut into kSubRanges
 // pieces with a work counter each, so that no more than 128 waves share a counter.

@@ -510,3 +510,19 @@ def test_random_generator_settings_slice(scanner):
             H.assert_streams_equal(fr, ac, ofr, oac)
         except AssertionError as e:
             raise AssertionError("setting %d first_buffer=%d %s: %s" % (k, first, {f[0]: getattr(cfg, f[0]) for f in cfg._fields_}, e))
+
+
+def test_one_scanner_inputs_of_changing_size(native_libs):
+    """The scan kernels add every chunk's record count into per-256-chunk sums that the ordering pass starts from; the sums live in two
+    arrays per slot that swap roles per call, each call's ordering pass zeroing the other one in full.  Large, small, empty and large
+    inputs through one scanner must all come out as the oracle's records (a stale sum would misplace every later record)."""
+    sc = A.Scanner(0)
+    BB = A.REF_BUFFER_BYTES
+    for k, nbuf in enumerate((96, 2, 0, 96, 1, 0, 0, 40, 96)):
+        if nbuf == 0:
+            got = sc.scan(np.zeros(0, dtype=np.uint8), BB)
+            assert len(got) == 0
+            continue
+        iq, _ = synth.fill_range(100 * k, nbuf, nthreads=8)
+        H.assert_records_equal(sc.scan(iq, BB), H.expected_records(iq, BB))
+    sc.close()
