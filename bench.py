@@ -168,7 +168,7 @@ def main():
                 u = bench_uat978(argparse.Namespace(**{**vars(args), "steps": max(5, min(args.steps, 30)), "warmup": min(args.warmup, 3)}),
                                  0, local_rank, 1, None, A, synth, torch)
                 out["uat978"] = {k: u[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "frames_per_step",
-                                                   "demod_kernel_ms", "dominant_kernel", "matches_per_step_rank0", "pipelined", "ms_per_step_serial",
+                                                   "demod_kernel_ms", "dominant_kernel", "matches_per_step_rank0", "pipelined", "ms_per_step_serial", "timing",
                                                    "host_wall_ms_last_step", "cpu_baseline") if k in u}
             except Exception as e:  # the headline line must not be lost to the second workload
                 out["uat978"] = {"error": repr(e)}
@@ -591,11 +591,14 @@ def bench_uat978(args, rank, local_rank, world, dist, A, synth, torch):
         elapsed = elapsed_serial
     else:
         run_pipelined(max(2, args.warmup))
-        barrier()
-        t0 = time.perf_counter()
-        run_pipelined(args.steps)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        windows = []
+        for _ in range(3):  # three timed windows of `steps` steps, the median reported: four host threads are involved and one
+            barrier()       # descheduled worker shows up as a 20-30 % slower window on a shared box
+            t0 = time.perf_counter()
+            run_pipelined(args.steps)
+            barrier()
+            windows.append(time.perf_counter() - t0)
+        elapsed = sorted(windows)[1]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -627,6 +630,7 @@ def bench_uat978(args, rank, local_rank, world, dist, A, synth, torch):
             "roofline": scan_roof,
             "frames_per_step": nframes_all, "demod_kernel_ms": round(demod_k, 4), "matches_per_step_rank0": int(matches),
             "pipelined": not args.serial, "ms_per_step_serial": round(elapsed_serial / args.steps * 1e3, 4),
+            "timing": "serial: one window of `steps` calls; pipelined (ms_per_step, value): median of three such windows",
             "host_wall_ms_last_step": tm["host_wall_ms"],
         }
         if demod_k > scan_k:
