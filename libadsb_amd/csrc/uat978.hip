@@ -282,6 +282,7 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
     {
         const uint64_t s0 = span * kUatWaveSamples;
         // ---- A: sign bits of [s0, s0 + 2048 + 64)
+        __builtin_amdgcn_s_setprio(0);
         if (fast(span))
         {
             uint32_t p01[kUatRows + 1], p23[kUatRows + 1], p45[kUatRows + 1], p67[kUatRows + 1];
@@ -295,6 +296,10 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
             p45[kUatRows] = lut2(lut_s, vh.z), p67[kUatRows] = lut2(lut_s, vh.w);
             const uint32_t after_all = lut_s[swz1(after_halo)];
             if (fast(span + nwaves)) load(span + nwaves); // everything of this span is in registers as phases now
+            // From here to the end of the span the wave has everything in registers or in its own corner of LDS; with raised priority it
+            // gets through that part ahead of the waves that are still issuing table gathers, and is back at issuing its own sooner:
+            // 0.2068 -> 0.2007 ms per GiB (in-process A/B; raising it for the gathers instead gives 0.2040, for the search alone 0.2055).
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int r = 0; r <= kUatRows; r++)
             { // a lane's ninth phase is the next lane's first (wave_shl:1); lane 63's is the next row's first (row 4 = halo, 8 lanes)
