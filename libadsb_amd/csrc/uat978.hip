@@ -652,46 +652,61 @@ __device__ int rs_decode_wave(const RsTables& T, int nr, int pad, uint8_t* data,
     const uint32_t syn = lane < nr ? w.s[lane] : 0u;
     if (__ballot(syn != 0) == 0) return 0;
 
-    // Berlekamp-Massey: lane i holds lambda[i] and b[i]
-    uint32_t lam = lane == 0, bb = lane == 0;
-    int      el  = 0;
+    // Berlekamp-Massey: lane i holds lambda[i] and b[i].  Kept beside their logarithms so that an iteration costs four table look-ups
+    // instead of nine: b is only ever multiplied (its value is needed as "zero or not" + logarithm), the syndrome window
+    // s[r-1-i] of lane i is last iteration's window of lane i-1 (a DPP shift of the value and of its logarithm, the new
+    // syndrome entering at lane 0), and b = lambda / discrepancy is a subtraction of logarithms.
+    const uint32_t lsyn = T.log[syn];
+    uint32_t       lam = lane == 0, llam = 0; // log[1] = 0
+    uint32_t       bnz = lane == 0, lbb = 0;
+    uint32_t       sv = 0, lsv = 0;
+    int            el = 0;
     for (int r = 1; r <= nr; r++)
     {
-        const uint32_t sv      = lane < r ? w.s[r - 1 - lane] : 0u;
-        const uint32_t discr   = (uint32_t)wave_xor_i((int)gf_mul(T, lam, sv));
-        const uint32_t b_shift = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bb, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-        if (discr == 0) bb = b_shift;
+        const uint32_t s_new = (uint32_t)__builtin_amdgcn_readlane((int)syn, r - 1), ls_new = (uint32_t)__builtin_amdgcn_readlane((int)lsyn, r - 1);
+        sv  = (uint32_t)__builtin_amdgcn_update_dpp((int)s_new, (int)sv, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+        lsv = (uint32_t)__builtin_amdgcn_update_dpp((int)ls_new, (int)lsv, 0x138, 0xF, 0xF, false);
+        const uint32_t term   = (lam && sv) ? (uint32_t)T.exp[llam + lsv] : 0u;
+        const uint32_t discr  = (uint32_t)wave_xor_i((int)term);
+        const uint32_t bs_nz  = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bnz, 0x138, 0xF, 0xF, false);
+        const uint32_t lbs    = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lbb, 0x138, 0xF, 0xF, false);
+        if (discr == 0) bnz = bs_nz, lbb = lbs;
         else
         {
-            const uint32_t t = lam ^ gf_mul(T, discr, b_shift);
+            const uint32_t ldis = T.log[discr];
+            const uint32_t t    = lam ^ (bs_nz ? (uint32_t)T.exp[ldis + lbs] : 0u);
             if (2 * el <= r - 1)
-            {
-                el = r - el;
-                bb = lam ? T.exp[T.log[lam] + 255 - T.log[discr]] : 0u;
+            { // b = lambda / discr
+                el             = r - el;
+                const uint32_t q = llam + 255u - ldis; // 1 .. 509
+                bnz = lam != 0, lbb = q >= 255u ? q - 255u : q;
             }
-            else bb = b_shift;
-            lam = t;
+            else bnz = bs_nz, lbb = lbs;
+            lam = t, llam = T.log[t];
         }
-        if (lane > nr) lam = 0, bb = 0;
+        if (lane > nr) lam = 0, bnz = 0;
     }
     const uint64_t nz  = __ballot(lam != 0);
     const int      deg = nz ? 63 - __builtin_clzll(nz) : 0;
     if (lane <= nr) w.lambda[lane] = (uint8_t)lam;
     wave_fence();
 
-    // Chien search: X^-1 = alpha^i for i = 1 .. 255, four per lane
-    int count = 0;
-#pragma unroll 1
+    // Chien search: X^-1 = alpha^i for i = 1 .. 255, four per lane; the coefficient and its logarithm are fetched once for the four
+    int      count = 0;
+    uint32_t q4[4] = {1, 1, 1, 1};
+    for (int j = 1; j <= deg; j++)
+    {
+        const uint32_t lj = w.lambda[j]; // uniform
+        if (lj == 0) continue;
+        const int ll = T.log[lj], step = j * (1 + lane);
+#pragma unroll
+        for (int k = 0; k < 4; k++) q4[k] ^= T.exp[gf_fold(ll + step + 64 * j * k)];
+    }
+#pragma unroll
     for (int k = 0; k < 4; k++)
     {
-        const int i = 1 + lane + 64 * k;
-        uint32_t  q = 1;
-        for (int j = 1; j <= deg; j++)
-        {
-            const uint32_t lj = w.lambda[j];
-            if (lj) q ^= T.exp[gf_fold(T.log[lj] + j * i)];
-        }
-        const bool     hit  = i <= 255 && q == 0;
+        const int      i    = 1 + lane + 64 * k;
+        const bool     hit  = i <= 255 && q4[k] == 0;
         const uint64_t hits = __ballot(hit);
         if (hit)
         {
