@@ -49,6 +49,7 @@ struct UatArgs
     uint8_t*        uplink_payloads; // uplink_cap x 432 bytes
     uint32_t        uplink_cap;
     uint32_t*       demod_work; // kUatDemodRanges work counters, 32 words apart
+    uint32_t        single_word; // launch_uat978_demod with cand == nullptr and ncand == 1: the one match word to demodulate
 };
 
 hipError_t launch_uat978(const UatArgs& a, hipStream_t stream);                       // signs + 18-bit match

@@ -795,7 +795,7 @@ __global__ __launch_bounds__(64, 5) void uat_demod_kernel(const uint16_t* __rest
                                                        const RsTables* __restrict__ rs_tables, const uint32_t* __restrict__ cand, uint32_t ncand,
                                                        uat_rec_t* __restrict__ recs, uint8_t* __restrict__ uplink_payloads, uint32_t uplink_cap,
                                                        uint32_t* __restrict__ uplink_count, uint32_t* __restrict__ work_counters, uint32_t nranges,
-                                                       const uint32_t* __restrict__ up_list, const uint32_t* __restrict__ up_count)
+                                                       const uint32_t* __restrict__ up_list, const uint32_t* __restrict__ up_count, uint32_t single_word)
 {
     __shared__ RsTables T;
     __shared__ uint8_t  raw[2][kUatUplinkBytes + 8];
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(64, 5) void uat_demod_kernel(const uint16_t* __rest
         const bool     from_list = item < nup_r;
         const uint32_t c         = from_list ? up_list[range + item * nranges] : first + (item - nup_r);
         item                     = next_item;
-        const uint32_t word = cand[c];
+        const uint32_t word = cand ? cand[c] : single_word; // cand == nullptr: one look-up the host asked for, passed by value
         const uint32_t kind = word >> 31;
         const uint64_t idx  = word & 0x7FFFFFFFu;
         const uint64_t sb   = idx >> 1;
@@ -1056,8 +1056,8 @@ hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, bool ordered, h
     const uint32_t nranges = ncand >= 4096 ? kUatDemodRanges : 1u;
     uint32_t       g       = ncand > 8192 ? 8192 : ncand;
     g                      = ((g + nranges - 1) / nranges) * nranges;
-    if (!ordered)
-    {
+    if (!ordered && ncand > 1)
+    { // (a single look-up needs no reset: one wave, one item, and the loop ends whatever the counter holds; the next ordering pass zeroes it)
         hipError_t e = hipMemsetAsync(a.demod_work, 0, kUatDemodRanges * 32 * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
     }
@@ -1065,10 +1065,10 @@ hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, bool ordered, h
     const uint32_t* up_count = ordered ? a.counts + 2 : nullptr;
     if (a.phases_given)
         hipLaunchKernelGGL(uat_demod_kernel<true>, dim3(g), dim3(64), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
-                           a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges, up_list, up_count);
+                           a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges, up_list, up_count, a.single_word);
     else
         hipLaunchKernelGGL(uat_demod_kernel<false>, dim3(g), dim3(64), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
-                           a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges, up_list, up_count);
+                           a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges, up_list, up_count, a.single_word);
     return hipGetLastError();
 }
 

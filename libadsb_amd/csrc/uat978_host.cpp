@@ -394,12 +394,31 @@ struct adsb_amd_uat
             if (!rc) rc = reserve_uplink(up_cap * 2 + 64);
             if (rc) return rc;
         }
-        counts_h[2] = (index & 0x7FFFFFFFu) | (kind << 31); // page-locked: the copy is ordered before the kernel on the stream
-        UAT_HIP(hipMemcpyAsync(sorted_d + nrecords, counts_h + 2, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        // One wave, the match word passed by value, the record straight back: a launch, a 64-byte copy and one wait (round 1 staged the
+        // word through a copy, reset the work counters and fetched the payload counter as well: six stream operations, ~50 us a look-up).
         stat_extra++;
         const uint32_t at = nrecords;
-        int            rc = demod_on_device(in_dev, n, phases_given, 1, at, false);
-        if (rc) return rc;
+        {
+            UatArgs a     = args(in_dev, n, phases_given);
+            a.cand        = nullptr;
+            a.single_word = (index & 0x7FFFFFFFu) | (kind << 31);
+            a.recs += at;
+            UAT_HIP(recs_h.reserve((size_t)at + 1, at));
+            UAT_HIP(launch_uat978_demod(a, 1, false, stream));
+            UAT_HIP(hipMemcpyAsync(recs_h.p + at, recs_d + at, sizeof(uat_rec_t), hipMemcpyDeviceToHost, stream));
+            UAT_HIP(hipStreamSynchronize(stream));
+            const uat_rec_t& r = recs_h.p[at];
+            if (r.kind == 1 && r.variant < 2)
+            { // its decoded payload sits in the next slot of the side array
+                if (r.slot >= up_cap) return fail(ADSB_AMD_EHIP, "UAT uplink payload area too small");
+                UAT_HIP(up_h.reserve((size_t)(r.slot + 1) * 432, (size_t)nuplink * 432));
+                UAT_HIP(hipMemcpyAsync(up_h.p + (size_t)nuplink * 432, up_d + (size_t)nuplink * 432, (size_t)(r.slot + 1 - nuplink) * 432,
+                                       hipMemcpyDeviceToHost, stream));
+                UAT_HIP(hipStreamSynchronize(stream));
+                nuplink = r.slot + 1;
+            }
+            nrecords = at + 1;
+        }
         extra[((uint64_t)index << 1) | kind] = at;
         *out                                 = at;
         return ADSB_AMD_OK;
