@@ -44,6 +44,10 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mib", type=int, default=1024, help="MiB of u8 IQ per GPU (weak scaling)")
     ap.add_argument("--cpu-buffers", type=int, default=4096, help="reference buffers in the CPU-baseline sample (0: skip)")
+    ap.add_argument("--sharded-step-on-one-rank", action="store_true", help="run the N > 1 step (scan, record hand-over, nccl) with a world of one, "
+                    "started under torch.distributed.run --nproc-per-node 1: the device path of the hand-over on a box with one GPU")
+    ap.add_argument("--rccl-gather", action="store_true", help="N > 1: gather the records themselves over RCCL to rank 0's GPU and copy them to its "
+                    "host from there (the round-2 first form), instead of every GPU writing into node-shared page-locked host memory")
     ap.add_argument("--serial", action="store_true", help="submit/fetch one step at a time (no overlap of the record copy with the next "
                     "scan); used for rocprofv3 runs, where the runtime's shader-based copy would otherwise co-run with the scan kernel")
     ap.add_argument("--workload", choices=["1090", "uat978"], default="1090", help="1090: the headline metric (BASELINE configs[1]+[2], and "
@@ -146,7 +150,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.sharded_step_on_one_rank:
         import torch.distributed as dist_mod
         dist = dist_mod
         if args.rehearse_on_one_gpu:
@@ -161,7 +165,7 @@ def main():
         out = bench_uat978(args, rank, local_rank, world, dist, A, synth, torch)
         if rank == 0:
             print(json.dumps(out), flush=True)
-    elif world == 1:
+    elif world == 1 and not args.sharded_step_on_one_rank:
         out = bench_1090_single(args, local_rank, A, synth, torch)
         if not args.no_extras:
             try:
@@ -406,7 +410,7 @@ def end_to_end_1090(A, rec, dec, iq_host, BB, nbuf, accepted):
 def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
     """BASELINE configs[3]: the recording is world x args.mib, rank r scans buffers [r*B/N, (r+1)*B/N), records gathered on rank 0."""
     import numpy as np
-    from libadsb_amd.shard import RootGather, shard_range
+    from libadsb_amd.shard import NodeGather, RootGather, shard_range
     BB = A.REF_BUFFER_BYTES
     nbuf_total = world * ((args.mib << 20) // BB)
     first, nbuf = shard_range(nbuf_total, rank, world)
@@ -426,9 +430,21 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
     capt = torch.tensor([n0 + n0 // 4 + 4096], dtype=torch.int64, device="cuda" if on_device else "cpu")
     dist.all_reduce(capt, op=dist.ReduceOp.MAX)
     cap = int(capt.item())
+    # How the records reach rank 0's host.  Default: every GPU writes its records over its own PCIe link into a page-locked segment
+    # of node-shared host memory and only 32-byte headers are gathered (shard.NodeGather) -- with a gather of the records themselves
+    # (shard.RootGather: xGMI to rank 0's GPU, then its one host link) rank 0's PCIe link carries N x 9 MB per step and bounds the job
+    # from N = 2 on.  --rccl-gather, or a node where the shared segment cannot be set up, uses the record gather.
+    ng = None
+    if not args.rccl_gather:
+        try:
+            ng = NodeGather(cap)
+        except OSError as e:
+            if rank == 0:
+                print("bench: node-shared record segments unavailable (%s), gathering the records over RCCL" % e, file=sys.stderr)
     rg = RootGather(cap)
+    step_no = [0]
 
-    def deliver(slot):
+    def deliver_rccl(slot):
         """Records of `slot` -> rank 0 (collective).  Device path: scanner -> send buffer (device to device, on the side stream) ->
         RCCL gather -> rank 0's page-locked host memory; the compute stream only waits for the first of those copies."""
         if on_device:
@@ -440,6 +456,23 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
         rec = sc.fetch(slot, copy=False)
         rg.host_records_view()[:len(rec)] = rec
         return rg.gather(len(rec), first)
+
+    def deliver_node(slot):
+        """Records of `slot` -> this rank's segment of the node-shared page-locked memory (device to host over the rank's own link, on
+        the side stream), then the header gather; rank 0 gets one view per rank, in recording order."""
+        step = step_no[0]
+        step_no[0] += 1
+        if on_device:
+            with torch.cuda.stream(comm):
+                n = sc.fetch_device(slot, ng.records_ptr(step), cap, comm.cuda_stream)
+                ev = comm.record_event()
+                compute.wait_event(ev)
+                return ng.gather(step, n, first)
+        rec = sc.fetch(slot, copy=False)
+        ng.host_records_view(step)[:len(rec)] = rec
+        return ng.gather(step, len(rec), first)
+
+    deliver = deliver_node if ng is not None else deliver_rccl
 
     def run(steps):
         k_ms = 0.0
@@ -475,6 +508,20 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
     rec = deliver(0)
     torch.cuda.synchronize()
     te = time.perf_counter()
+    rccl_serial = te - tg
+    transports_agree = None
+    if ng is not None:
+        # the record gather over RCCL, once, for comparison (serial: scan, then gather, nothing overlapped)
+        barrier()
+        sc.submit(d_iq.data_ptr(), nbytes, BB, compute.cuda_stream, 0)
+        torch.cuda.synchronize()
+        tr = time.perf_counter()
+        rec_rccl = deliver_rccl(0)
+        torch.cuda.synchronize()
+        rccl_serial = time.perf_counter() - tr
+        if rank == 0:
+            rec = NodeGather.concatenate(rec)
+            transports_agree = bool(len(rec) == len(rec_rccl) and rec.tobytes() == rec_rccl.tobytes())
     # the round-1 definition for comparison: independent shards, records to each rank's own host, no gather
     run1 = make_runner(args, sc, d_iq, BB, compute.cuda_stream)
     run1(5)
@@ -485,9 +532,9 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
     indep = time.perf_counter() - t1
 
     dev = "cuda" if on_device else "cpu"
-    t = torch.tensor([elapsed, indep, tg - ts, te - tg], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, indep, tg - ts, te - tg, rccl_serial], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, indep, scan_serial, gather_serial = [float(x) for x in t.tolist()]
+    elapsed, indep, scan_serial, gather_serial, rccl_serial = [float(x) for x in t.tolist()]
     c = torch.tensor([injected, k_ms / args.steps * 1e3], dtype=torch.float64, device=dev)
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     injected_all, kernel_us_sum = int(c[0].item()), float(c[1].item())
@@ -510,18 +557,25 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
             "warmup": args.warmup, "setup_steps": SETUP_STEPS, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 in / u16 integer (bit-exact)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: recorded-file case, %d MiB recording = " % (world * args.mib) + WORKLOAD_1090 % (args.mib, nbuf)
-                                   + "; rank r scans buffers [r*B/N, (r+1)*B/N), sorted records of all ranks gathered on rank 0 (%s, one "
-                                     "fixed-size gather per step, device to device) and copied to its host memory in recording order"
-                                   % ("RCCL over xGMI" if on_device else "gloo: REHEARSAL on one GPU, numbers meaningless"),
+                                   + "; rank r scans buffers [r*B/N, (r+1)*B/N), sorted records of all ranks delivered to rank 0's host in "
+                                     "recording order: %s (%s)"
+                                   % ("every GPU writes its records over its own PCIe link into a page-locked segment of node-shared host memory, "
+                                      "one gather of 32-byte headers per step" if ng is not None else
+                                      "one fixed-size gather of the records per step, device to device, then rank 0's GPU -> its host",
+                                      "RCCL over xGMI" if on_device else "gloo: REHEARSAL on one GPU, numbers meaningless"),
                        "bytes_per_gpu": nbytes, "buffers_per_gpu": nbuf, "buffers_total": nbuf_total,
-                       "sharding": "contiguous buffer ranges, no halo, no collective on the sample path; one record gather per step", "pipelined": True},
+                       "sharding": "contiguous buffer ranges, no halo, no collective on the sample path; per step one %s" %
+                                   ("header gather (records go host-side through node-shared memory)" if ng is not None else "record gather"),
+                       "record_transport": "node-shared page-locked host segments" if ng is not None else "RCCL record gather", "pipelined": True},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic(nbytes), "kernel": "scan1090_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes": int(alg_bytes), "note": "per GPU, mean over ranks"},
             "records_per_step": nrec, "frames_injected": injected_all, "decoded_msgs_per_step": int(accepted),
-            "serial_step_ms": {"scan_and_order": round(scan_serial * 1e3, 4), "gather_to_rank0_host": round(gather_serial * 1e3, 4)},
+            "serial_step_ms": {"scan_and_order": round(scan_serial * 1e3, 4), "records_to_rank0_host": round(gather_serial * 1e3, 4),
+                               "records_to_rank0_host_by_rccl_record_gather": round(rccl_serial * 1e3, 4)},
             "resolve_ms_rank0": round(resolve_s * 1e3, 2),
             "independent_shards_value": round(samples_all * args.steps / indep / 1e6, 1),
+            "record_transports_agree": transports_agree,
             "gather_bytes_per_step": int(nrec * 32),
         }
     sc.close()

@@ -418,7 +418,8 @@ extern "C" int adsb_amd_scan_1090_fetch_device(adsb_amd_ctx_t* c, int slot, void
         if (s.nrecords)
         {
             hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->copy_stream;
-            HIP_TRY(c, hipMemcpyAsync(dst_device, s.dense, s.nrecords * sizeof(adsb_amd_record_t), hipMemcpyDeviceToDevice, st));
+            // hipMemcpyDefault: the destination may be device memory or page-locked / registered host memory (shard.NodeGather)
+            HIP_TRY(c, hipMemcpyAsync(dst_device, s.dense, s.nrecords * sizeof(adsb_amd_record_t), hipMemcpyDefault, st));
             if (!hip_stream) HIP_TRY(c, hipStreamSynchronize(st));
         }
         s.timed = true;

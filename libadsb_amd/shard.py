@@ -9,7 +9,14 @@ arrays to the rank that runs the sequential resolver -- RCCL over xGMI with back
   RootGather          only the root receives it: one fixed-size dist.gather per step, the record count travels in a
                       32-byte header in front of the records, so there is no separate count exchange; on "nccl" the payload
                       goes device to device (the scanner copies its sorted records straight into the send buffer)
+  NodeGather          the same result on one node without funnelling the records through the root's GPU: every rank's GPU writes
+                      its records over its own PCIe link into a page-locked segment of node-shared host memory, only the 32-byte
+                      headers are gathered (RCCL).  With RootGather the root's one host link carries N x 9 MB per GiB-step and
+                      bounds the job from N = 2 on; here it carries 9 MB whatever N is.
 """
+import mmap
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -112,3 +119,116 @@ class RootGather:
                 rec["buffer"][at:at + n] += f
             at += n
         return rec
+
+
+class NodeGather:
+    """Per-step hand-over of every rank's sorted records to rank `root` through node-shared page-locked host memory.
+
+    One file in /dev/shm holds world x 2 segments of cap records (two, so that the ranks can fill step k + 1 while the root still
+    reads step k); every rank maps it and registers the mapping with the HIP runtime, so its scanner copies the step's records
+    straight from HBM into its segment (`records_ptr(step)`) over its own PCIe link.  `gather(step, count, first_buffer)` then gathers
+    only a 32-byte header per rank (RCCL on "nccl", on the same stream as the copy, so a header that has arrived implies the records
+    have) and returns on the root one (records view, first buffer) pair per rank, in rank = recording order; `concatenate` makes one
+    array with recording-wide buffer indices out of them.  Raises at construction when the segment cannot be set up (no /dev/shm
+    space, registration refused): callers fall back to RootGather.
+    """
+
+    def __init__(self, cap_records, root=0, group=None, tag=None):
+        self.group, self.root, self.cap = group, root, int(cap_records)
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.on_device = dist.get_backend(group) == "nccl"
+        self.seg = self.cap * REC
+        total = self.world * 2 * self.seg
+        tag = tag or os.environ.get("MASTER_PORT", "0")
+        self.path = "/dev/shm/libadsb_amd_gather_%s_%d" % (tag, os.getuid())
+        dev = torch.device("cuda", torch.cuda.current_device()) if self.on_device else torch.device("cpu")
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        self._map = None
+        self._registered = False
+        try:
+            if self.rank == root:
+                fd = os.open(self.path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+                try:
+                    os.posix_fallocate(fd, 0, total)  # fails here, not with SIGBUS on first touch, when /dev/shm is too small
+                finally:
+                    os.close(fd)
+        except OSError:
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)  # also the barrier after which the file exists
+        if int(ok.item()):
+            try:
+                fd = os.open(self.path, os.O_RDWR)
+                try:
+                    self._map = mmap.mmap(fd, total)
+                finally:
+                    os.close(fd)
+                self._np = np.frombuffer(self._map, dtype=np.uint8)
+                if self.on_device:
+                    rc = torch.cuda.cudart().cudaHostRegister(self._np.ctypes.data, total, 0)
+                    if int(rc) != 0:
+                        raise OSError("hipHostRegister failed (%s)" % (rc,))
+                    self._registered = True
+            except (OSError, ValueError, RuntimeError):
+                ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if self.rank == root and os.path.exists(self.path):
+            os.unlink(self.path)  # every rank holds its mapping; the name is not needed any more
+        if not int(ok.item()):
+            self.close()
+            raise OSError("node-shared record segment could not be set up on every rank")
+        self._hdr_h = torch.zeros(4, dtype=torch.int64).pin_memory() if self.on_device else torch.zeros(4, dtype=torch.int64)
+        self._hdr = torch.zeros(4, dtype=torch.int64, device=dev)
+        self._parts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(self.world)] if self.rank == root else None
+
+    def _offset(self, rank, step):
+        return (rank * 2 + (step & 1)) * self.seg
+
+    def records_ptr(self, step):
+        """Host address (page-locked, device-writable) where this rank's records of `step` go."""
+        return self._np.ctypes.data + self._offset(self.rank, step)
+
+    def host_records_view(self, step):
+        """numpy view of this rank's segment for `step` (gloo/CPU mode: fill it, then call gather)."""
+        o = self._offset(self.rank, step)
+        return self._np[o:o + self.seg].view(RECORD_DTYPE)
+
+    def gather(self, step, count, first_buffer):
+        """Collective; on "nccl" call it on the stream the records were copied on.  Returns on the root [(records, first_buffer)] per
+        rank (views of the shared segments, valid until step + 2 is written), elsewhere None."""
+        if count > self.cap:
+            raise RuntimeError("rank %d produced %d records, its segment holds %d" % (self.rank, count, self.cap))
+        self._hdr_h[0], self._hdr_h[1] = int(count), int(first_buffer)
+        self._hdr.copy_(self._hdr_h, non_blocking=True)
+        dist.gather(self._hdr, self._parts, dst=self.root, group=self.group)
+        if self.rank != self.root:
+            return None
+        heads = torch.stack(self._parts).cpu().numpy()  # waits for the gather, hence for every rank's copy
+        out = []
+        for r in range(self.world):
+            o = self._offset(r, step)
+            n = int(heads[r][0])
+            out.append((self._np[o:o + n * REC].view(RECORD_DTYPE), int(heads[r][1])))
+        return out
+
+    @staticmethod
+    def concatenate(parts):
+        """One array with recording-wide buffer indices from what gather returned."""
+        recs = []
+        for rec, first in parts:
+            rec = rec.copy()
+            if first:
+                rec["buffer"] += first
+            recs.append(rec)
+        return np.concatenate(recs) if recs else np.zeros(0, RECORD_DTYPE)
+
+    def close(self):
+        if self._registered:
+            torch.cuda.cudart().cudaHostUnregister(self._np.ctypes.data)
+            self._registered = False
+        self._np = None
+        if self._map is not None:
+            try:
+                self._map.close()
+            except BufferError:
+                pass  # views handed out are still alive; the mapping goes with the process
+            self._map = None

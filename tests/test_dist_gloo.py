@@ -46,6 +46,28 @@ except RuntimeError:
     pass
 if rank == 0:
     print('ROOT-GATHER-OK')
+# the node-local form: every rank fills its own segment of shared memory, only headers are gathered
+ng = shard.NodeGather(1000)
+for step in range(5):
+    keep = len(local) - (step %% 3)  # a different count per step: stale records of step - 2 must not leak
+    ng.host_records_view(step)[:keep] = local[:keep]
+    parts = ng.gather(step, keep, first)
+    if rank == 0:
+        assert [f for _, f in parts] == [shard.shard_range(NBUF, r, world)[0] for r in range(world)]
+        got = shard.NodeGather.concatenate(parts)
+        assert len(parts[0][0]) == keep
+        mine = np.array(local[:keep]); H.assert_records_equal(got[:keep], mine)
+        if step %% 3 == 0:
+            H.assert_records_equal(got, allrec)
+    else:
+        assert parts is None
+try:
+    shard.NodeGather(3, tag='small').gather(0, 4, 0)
+    raise SystemExit('an over-full segment must raise')
+except RuntimeError:
+    pass
+if rank == 0:
+    print('NODE-GATHER-OK')
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -68,7 +90,7 @@ def test_two_rank_gather_and_resolve(tmp_path, native_libs):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29517", str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    assert "OK" in out.stdout and "ROOT-GATHER-OK" in out.stdout
+    assert "OK" in out.stdout and "ROOT-GATHER-OK" in out.stdout and "NODE-GATHER-OK" in out.stdout
 
 
 def test_bench_started_bare_launches_its_own_ranks(monkeypatch):

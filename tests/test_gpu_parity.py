@@ -388,6 +388,21 @@ for first in (0, 40):
     w = want.copy(); w["buffer"] += first
     assert rec.dtype == w.dtype and np.array_equal(rec, w), "gathered records differ"
 print("NCCL-OK", len(want))
+# the node-local hand-over: the GPU writes the records into a registered /dev/shm mapping, only the header is gathered
+from libadsb_amd.shard import NodeGather
+ng = NodeGather(len(want) + 64)
+comm = torch.cuda.Stream()
+for step, first in enumerate((0, 40, 7, 0, 3)):
+    sc.submit(d.data_ptr(), d.numel(), BB, st.cuda_stream, step & 1)
+    with torch.cuda.stream(comm):
+        n = sc.fetch_device(step & 1, ng.records_ptr(step), ng.cap, comm.cuda_stream)
+        parts = ng.gather(step, n, first)
+    assert len(parts) == 1 and parts[0][1] == first
+    rec = NodeGather.concatenate(parts)
+    w = want.copy(); w["buffer"] += first
+    assert rec.dtype == w.dtype and np.array_equal(rec, w), "records handed over through node-shared memory differ"
+ng.close()
+print("NODE-OK", len(want))
 dist.destroy_process_group()
 """
 
@@ -403,7 +418,7 @@ def test_root_gather_over_rccl_world_of_one(native_libs, tmp_path):
     out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29533",
                 str(script)])
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
-    assert "NCCL-OK" in out.stdout
+    assert "NCCL-OK" in out.stdout and "NODE-OK" in out.stdout
 
 
 def test_device_field_decoder_equals_the_host_build(scanner):
