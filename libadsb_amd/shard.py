@@ -147,9 +147,15 @@ class NodeGather:
         self._registered = False
         try:
             if self.rank == root:
+                # The file is only sized here; its pages are allocated when a rank first writes its own segments below, i.e. on the
+                # NUMA node that rank runs on, next to its GPU.  tmpfs would answer a write it has no room for with SIGBUS, so the room
+                # is checked first.
+                vfs = os.statvfs("/dev/shm")
+                if vfs.f_bavail * vfs.f_frsize < total + (64 << 20):
+                    raise OSError("not enough room in /dev/shm")
                 fd = os.open(self.path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
                 try:
-                    os.posix_fallocate(fd, 0, total)  # fails here, not with SIGBUS on first touch, when /dev/shm is too small
+                    os.ftruncate(fd, total)
                 finally:
                     os.close(fd)
         except OSError:
@@ -163,6 +169,9 @@ class NodeGather:
                 finally:
                     os.close(fd)
                 self._np = np.frombuffer(self._map, dtype=np.uint8)
+                for step in (0, 1):  # first touch of this rank's own segments
+                    o = self._offset(self.rank, step)
+                    self._np[o:o + self.seg] = 0
                 if self.on_device:
                     rc = torch.cuda.cudart().cudaHostRegister(self._np.ctypes.data, total, 0)
                     if int(rc) != 0:
