@@ -156,9 +156,10 @@ int adsb_amd_scan_1090_fetch(adsb_amd_ctx_t* ctx, int slot, const adsb_amd_recor
 /* fetch plus the decoded fields of every record (same order, same lifetime as the record pointer). */
 int adsb_amd_scan_1090_fetch_decoded(adsb_amd_ctx_t* ctx, int slot, const adsb_amd_record_t** records, const adsb_amd_decoded_t** decoded,
                                      size_t* n);
-/* The same wait, but the sorted records are copied device-to-device into `dst_device` (room for `cap` records, same GPU) on
- * `hip_stream` (NULL: an internal stream, and the call returns after the copy has completed): for consumers that stay on the
- * GPU, e.g. the RCCL gather of the sharded recorded-file case.  ADSB_AMD_ENOSPC when cap is too
+/* The same wait, but the sorted records are copied into `dst_device` (room for `cap` records: memory of the same GPU, or page-locked /
+ * HIP-registered host memory) on `hip_stream` (NULL: an internal stream, and the call returns after the copy has completed): for the
+ * hand-over of the sharded recorded-file case -- an RCCL gather of the records from device buffers, or every
+ * GPU writing into its segment of node-shared host memory (libadsb_amd/shard.py).  ADSB_AMD_ENOSPC when cap is too
  * small (*n holds the count) or when a chunk region overflowed (use adsb_amd_scan_1090_fetch, which repeats the scan). */
 int adsb_amd_scan_1090_fetch_device(adsb_amd_ctx_t* ctx, int slot, void* dst_device, size_t cap, void* hip_stream, size_t* n);
 /* Device time of the last completed scan on `slot`: the demodulation kernel alone, and submit-to-records-on-host. */
