@@ -169,7 +169,7 @@ def main():
         out = bench_1090_single(args, local_rank, A, synth, torch)
         if not args.no_extras:
             try:
-                u = bench_uat978(argparse.Namespace(**{**vars(args), "steps": max(5, min(args.steps, 30)), "warmup": min(args.warmup, 3)}),
+                u = bench_uat978(argparse.Namespace(**{**vars(args), "steps": max(5, min(args.steps, 100)), "warmup": min(args.warmup, 3)}),
                                  0, local_rank, 1, None, A, synth, torch)
                 out["uat978"] = {k: u[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "frames_per_step",
                                                    "demod_kernel_ms", "dominant_kernel", "matches_per_step_rank0", "pipelined", "ms_per_step_serial", "timing",
