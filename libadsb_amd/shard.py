@@ -74,7 +74,11 @@ class RootGather:
         self.send = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         self.parts = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(self.world)] if self.rank == root else None
         self.host = torch.zeros(self.world * nbytes, dtype=torch.uint8).pin_memory() if (self.rank == root and self.on_device) else None
-        self._hdr = torch.zeros(REC, dtype=torch.uint8).pin_memory() if self.on_device else torch.zeros(REC, dtype=torch.uint8)
+        # The header goes to the device by an asynchronous copy; a non-root rank does not wait for it, so the page-locked source of
+        # step k must not be rewritten for step k + 1 before the copy has run: a small ring (a rank is never more than the scanner's
+        # two slots ahead of its own side stream)
+        self._hdrs = [torch.zeros(REC, dtype=torch.uint8).pin_memory() if self.on_device else torch.zeros(REC, dtype=torch.uint8) for _ in range(4)]
+        self._calls = 0
 
     def records_ptr(self):
         """Device (or host) address where this rank's records of the step go: right behind the header."""
@@ -90,9 +94,11 @@ class RootGather:
         next call), elsewhere None."""
         if count > self.cap:
             raise RuntimeError("rank %d produced %d records, send buffer holds %d" % (self.rank, count, self.cap))
-        hdr = self._hdr.numpy().view(np.uint64)
+        src = self._hdrs[self._calls & 3]
+        self._calls += 1
+        hdr = src.numpy().view(np.uint64)
         hdr[0], hdr[1] = count, first_buffer
-        self.send[:REC].copy_(self._hdr, non_blocking=True)
+        self.send[:REC].copy_(src, non_blocking=True)
         dist.gather(self.send, self.parts, dst=self.root, group=self.group)
         if self.rank != self.root:
             return None
@@ -185,7 +191,8 @@ class NodeGather:
         if not int(ok.item()):
             self.close()
             raise OSError("node-shared record segment could not be set up on every rank")
-        self._hdr_h = torch.zeros(4, dtype=torch.int64).pin_memory() if self.on_device else torch.zeros(4, dtype=torch.int64)
+        # ring of page-locked header sources, see RootGather
+        self._hdrs_h = [torch.zeros(4, dtype=torch.int64).pin_memory() if self.on_device else torch.zeros(4, dtype=torch.int64) for _ in range(4)]
         self._hdr = torch.zeros(4, dtype=torch.int64, device=dev)
         self._parts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(self.world)] if self.rank == root else None
 
@@ -206,8 +213,9 @@ class NodeGather:
         rank (views of the shared segments, valid until step + 2 is written), elsewhere None."""
         if count > self.cap:
             raise RuntimeError("rank %d produced %d records, its segment holds %d" % (self.rank, count, self.cap))
-        self._hdr_h[0], self._hdr_h[1] = int(count), int(first_buffer)
-        self._hdr.copy_(self._hdr_h, non_blocking=True)
+        src = self._hdrs_h[step & 3]
+        src[0], src[1] = int(count), int(first_buffer)
+        self._hdr.copy_(src, non_blocking=True)
         dist.gather(self._hdr, self._parts, dst=self.root, group=self.group)
         if self.rank != self.root:
             return None
