@@ -578,6 +578,8 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
             "record_transports_agree": transports_agree,
             "gather_bytes_per_step": int(nrec * 32),
         }
+    if ng is not None:
+        ng.close()
     sc.close()
     return out
 
