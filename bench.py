@@ -467,22 +467,28 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
                 n = sc.fetch_device(slot, ng.records_ptr(step), cap, comm.cuda_stream)
                 ev = comm.record_event()
                 compute.wait_event(ev)
-                return ng.gather(step, n, first)
+                return ng.gather(step, n, first, wait=False)
         rec = sc.fetch(slot, copy=False)
         ng.host_records_view(step)[:len(rec)] = rec
-        return ng.gather(step, len(rec), first)
+        return ng.gather(step, len(rec), first, wait=False)
 
     deliver = deliver_node if ng is not None else deliver_rccl
 
+    def settle(out):
+        """rank 0 takes delivery of a step (shared segments: waits for the step's headers; record gather: already complete)"""
+        return out.result() if hasattr(out, "result") else out
+
     def run(steps):
         k_ms = 0.0
-        out = None
+        out = prev = None
         sc.submit(d_iq.data_ptr(), nbytes, BB, compute.cuda_stream, 0)
         for i in range(1, steps):
             sc.submit(d_iq.data_ptr(), nbytes, BB, compute.cuda_stream, i & 1)
-            out = deliver((i - 1) & 1)
+            settle(prev)  # rank 0 takes the step before (its hand-over ran beside a scan) BEFORE it posts the next header gather:
+            prev = deliver((i - 1) & 1)  # only then may a rank that runs ahead start overwriting that step's segment
             k_ms += sc.timing((i - 1) & 1)[0]
-        out = deliver((steps - 1) & 1)
+        settle(prev)
+        out = settle(deliver((steps - 1) & 1))
         return out, k_ms + sc.timing((steps - 1) & 1)[0]
 
     def barrier():
@@ -505,7 +511,7 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
     sc.submit(d_iq.data_ptr(), nbytes, BB, compute.cuda_stream, 0)
     torch.cuda.synchronize()
     tg = time.perf_counter()
-    rec = deliver(0)
+    rec = settle(deliver(0))
     torch.cuda.synchronize()
     te = time.perf_counter()
     rccl_serial = te - tg

@@ -127,6 +127,19 @@ class RootGather:
         return rec
 
 
+class _PendingParts:
+    """What NodeGather.gather(wait=False) returns on the root: result() waits for the step's headers (hence for every rank's
+    copy) and returns the per-rank views."""
+
+    def __init__(self, owner, step, heads_h, event):
+        self.owner, self.step, self.heads_h, self.event = owner, step, heads_h, event
+
+    def result(self):
+        if self.event is not None:
+            self.event.synchronize()
+        return self.owner._views(self.step, self.heads_h.numpy())
+
+
 class NodeGather:
     """Per-step hand-over of every rank's sorted records to rank `root` through node-shared page-locked host memory.
 
@@ -195,6 +208,7 @@ class NodeGather:
         self._hdrs_h = [torch.zeros(4, dtype=torch.int64).pin_memory() if self.on_device else torch.zeros(4, dtype=torch.int64) for _ in range(4)]
         self._hdr = torch.zeros(4, dtype=torch.int64, device=dev)
         self._parts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(self.world)] if self.rank == root else None
+        self._heads_h = [torch.zeros(self.world, 4, dtype=torch.int64).pin_memory() for _ in range(4)] if (self.rank == root and self.on_device) else None
 
     def _offset(self, rank, step):
         return (rank * 2 + (step & 1)) * self.seg
@@ -208,9 +222,11 @@ class NodeGather:
         o = self._offset(self.rank, step)
         return self._np[o:o + self.seg].view(RECORD_DTYPE)
 
-    def gather(self, step, count, first_buffer):
+    def gather(self, step, count, first_buffer, wait=True):
         """Collective; on "nccl" call it on the stream the records were copied on.  Returns on the root [(records, first_buffer)] per
-        rank (views of the shared segments, valid until step + 2 is written), elsewhere None."""
+        rank (views of the shared segments, valid until step + 2 is written), elsewhere None.  wait=False: the root gets a handle
+        whose result() gives the same once the step's headers have arrived -- so that it can enqueue step k + 1 before it looks at
+        step k, like the other ranks do."""
         if count > self.cap:
             raise RuntimeError("rank %d produced %d records, its segment holds %d" % (self.rank, count, self.cap))
         src = self._hdrs_h[step & 3]
@@ -219,7 +235,17 @@ class NodeGather:
         dist.gather(self._hdr, self._parts, dst=self.root, group=self.group)
         if self.rank != self.root:
             return None
-        heads = torch.stack(self._parts).cpu().numpy()  # waits for the gather, hence for every rank's copy
+        if self.on_device:
+            heads_h = self._heads_h[step & 3]
+            heads_h.copy_(torch.stack(self._parts), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            heads_h, ev = torch.stack(self._parts).clone(), None
+        pending = _PendingParts(self, step, heads_h, ev)
+        return pending.result() if wait else pending
+
+    def _views(self, step, heads):
         out = []
         for r in range(self.world):
             o = self._offset(r, step)
