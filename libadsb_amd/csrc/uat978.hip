@@ -969,8 +969,22 @@ __global__ __launch_bounds__(1024) void uat_order_prefix_kernel(uint32_t* __rest
     if (threadIdx.x < kUatDemodRanges) demod_work[threadIdx.x * 32u] = 0; // the demodulation pass that follows starts from zero
     if (threadIdx.x == 0) *up_count = 0;
     const uint32_t      per = (nspans + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < nspans ? lo + per : nspans;
-    uint32_t            sum = 0;
-    for (uint32_t k = lo; k < hi; k++) sum += span_count[k];
+    // a slice that is a whole number of 16-byte groups inside the array goes through registers in one burst of loads (a dependent
+    // load per bin made this one-workgroup kernel 20 us long); anything else takes the plain loops
+    const bool vec = (per % 4u == 0u) && per <= 32u && lo + per <= nspans;
+    uint4      reg[8];
+    uint32_t   sum = 0;
+    if (vec)
+    {
+#pragma unroll
+        for (uint32_t g = 0; g < 8; g++)
+            if (4u * g < per) reg[g] = reinterpret_cast<const uint4*>(span_count + lo)[g];
+#pragma unroll
+        for (uint32_t g = 0; g < 8; g++)
+            if (4u * g < per) sum += reg[g].x + reg[g].y + reg[g].z + reg[g].w;
+    }
+    else
+        for (uint32_t k = lo; k < hi; k++) sum += span_count[k];
     partial[threadIdx.x] = sum;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1)
@@ -981,12 +995,27 @@ __global__ __launch_bounds__(1024) void uat_order_prefix_kernel(uint32_t* __rest
         __syncthreads();
     }
     uint32_t run = partial[threadIdx.x] - sum;
-    for (uint32_t k = lo; k < hi; k++)
+    if (vec)
     {
-        const uint32_t c = span_count[k];
-        span_count[k]    = run;
-        run += c;
+#pragma unroll
+        for (uint32_t g = 0; g < 8; g++)
+            if (4u * g < per)
+            {
+                uint4 o;
+                o.x = run, run += reg[g].x;
+                o.y = run, run += reg[g].y;
+                o.z = run, run += reg[g].z;
+                o.w = run, run += reg[g].w;
+                reinterpret_cast<uint4*>(span_count + lo)[g] = o;
+            }
     }
+    else
+        for (uint32_t k = lo; k < hi; k++)
+        {
+            const uint32_t c = span_count[k];
+            span_count[k]    = run;
+            run += c;
+        }
 }
 
 // span_offset[] is the exclusive prefix; span_fill[] counts what has been placed (zeroed by the caller)
@@ -1004,22 +1033,75 @@ __global__ __launch_bounds__(256) void uat_order_within_kernel(const uint32_t* _
                                                                uint32_t nspans, uint32_t* __restrict__ sorted, uint32_t* __restrict__ up_list,
                                                                uint32_t* __restrict__ up_count)
 {
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nspans; s += gridDim.x * blockDim.x)
+    // one lane per bin; every wave runs the same number of trips so that the uplink reservation below sees all 64 lanes
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t s0 = blockIdx.x * blockDim.x + threadIdx.x - lane; s0 < nspans; s0 += gridDim.x * blockDim.x)
     {
-        const uint32_t n = span_fill[s];
-        if (n == 0) continue;
-        uint32_t* a = sorted + span_offset[s];
-        for (uint32_t i = 1; i < n; i++)
-        { // by sample index; two entries never share one (the check words are complements)
-            const uint32_t v = a[i], key = v & 0x7FFFFFFFu;
-            uint32_t       j = i;
-            for (; j > 0 && (a[j - 1] & 0x7FFFFFFFu) > key; j--) a[j] = a[j - 1];
-            a[j] = v;
+        const uint32_t s   = s0 + lane;
+        const uint32_t n   = s < nspans ? span_fill[s] : 0u;
+        const uint32_t off = s < nspans ? span_offset[s] : 0u;
+        uint32_t*      a   = sorted + off;
+        uint32_t       v[8];
+        uint32_t       ups = 0; // uplink matches of this bin
+        if (n <= 8)
+        { // the usual bin (five matches on a frame-dense stream): all of it in registers with one burst of loads, an odd-even
+          // transposition network on the sample index (absent entries sort to the end), one burst of stores -- the in-memory
+          // insertion sort below pays a dependent global load per comparison
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) v[i] = i < n ? a[i] : 0xFFFFFFFFu; // no match word is all ones (index < 2^31 - 36)
+            auto key = [](uint32_t x) { return x == 0xFFFFFFFFu ? 0xFFFFFFFFu : (x & 0x7FFFFFFFu); };
+#pragma unroll
+            for (uint32_t round = 0; round < 8; round++)
+#pragma unroll
+                for (uint32_t i = round & 1u; i + 1 < 8; i += 2)
+                {
+                    const bool     swap = key(v[i]) > key(v[i + 1]);
+                    const uint32_t lo = swap ? v[i + 1] : v[i], hi = swap ? v[i] : v[i + 1];
+                    v[i] = lo, v[i + 1] = hi;
+                }
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++)
+                if (i < n)
+                {
+                    a[i] = v[i];
+                    ups += v[i] >> 31;
+                }
         }
-        // positions of the uplink matches: the demodulation pass takes these first (they cost ten times an ADS-B match, and one
-        // that starts last would be the kernel's tail)
-        for (uint32_t i = 0; i < n; i++)
-            if (a[i] >> 31) up_list[atomicAdd(up_count, 1u)] = span_offset[s] + i;
+        else
+        {
+            for (uint32_t i = 1; i < n; i++)
+            { // by sample index; two entries never share one (the check words are complements)
+                const uint32_t x = a[i], key = x & 0x7FFFFFFFu;
+                uint32_t       j = i;
+                for (; j > 0 && (a[j - 1] & 0x7FFFFFFFu) > key; j--) a[j] = a[j - 1];
+                a[j] = x;
+            }
+            for (uint32_t i = 0; i < n; i++) ups += a[i] >> 31;
+        }
+        // Positions of the uplink matches: the demodulation pass takes these first (they cost ten times an ADS-B match, and one that
+        // starts last would be the kernel's tail).  One reservation per wave: an atomic with a reply per match on the one counter
+        // (3 700 per GiB) was most of this kernel's 27 us.
+        uint32_t incl = ups;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1)
+        {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total == 0) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(up_count, total);
+        uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + incl - ups;
+        if (n <= 8)
+        {
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++)
+                if (i < n && (v[i] >> 31)) up_list[slot++] = off + i;
+        }
+        else
+            for (uint32_t i = 0; i < n; i++)
+                if (a[i] >> 31) up_list[slot++] = off + i;
     }
 }
 
