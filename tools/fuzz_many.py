@@ -67,3 +67,18 @@ for k in range(n3):
         pos += n
     uu.close()
 print("978: %d random generator settings / call sizes identical to the oracle (%.0f s)" % (n3, time.time() - t), flush=True)
+
+# the 2.4 MS/s mode against its specification, random generator settings
+sc24 = A.Scanner(mode=A.MODE_2400)
+t = time.time()
+for k in range(n3):
+    cfg = synth.default_cfg(noise_amp=int(rng.integers(0, 40)), mean_spacing=int(rng.choice([0, 250, 600, 2000, 20000])),
+                            amp_lo=int(rng.integers(5, 100)), amp_hi=int(rng.integers(100, 129)), pct_df17=int(rng.integers(0, 60)),
+                            pct_df11=int(rng.integers(0, 40)), pct_bitflip=int(rng.integers(0, 100)))
+    iq, _ = synth.fill_range(int(rng.integers(0, 10**6)), 3, cfg=cfg, rate_x10=24)
+    got = sc24.scan(iq, BB)
+    want = O.expected_records2400(iq, BB, dtype=A.RECORD_DTYPE)
+    assert len(got) == len(want) and got.tobytes() == want.tobytes(), ("mode 2400", k)
+    if k % 20 == 19:
+        print("  2400: %d settings so far" % (k + 1), flush=True)
+print("2400: %d random generator settings identical to the specification (%.0f s)" % (n3, time.time() - t), flush=True)
