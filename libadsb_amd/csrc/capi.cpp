@@ -37,7 +37,7 @@ thread_local std::string g_create_error;
 
 struct Slot
 {
-    uint32_t*          counts   = nullptr; // per chunk
+    uint32_t*          counts   = nullptr; // the chunk directory: {first raw record, records kept} per chunk
     uint32_t*          block_sums = nullptr; // two arrays of one padded entry per 256 chunks: the scan adds into one, the ordering pass zeroes the other
     size_t             sums_words = 0;       // words per array
     int                sums_phase = 0;       // which array the next scan uses
@@ -45,7 +45,7 @@ struct Slot
     adsb_amd_record_t* dense    = nullptr;
     adsb_amd_decoded_t* decoded = nullptr; // parallel to dense
     adsb_amd_packed_t*  packed  = nullptr; // parallel to dense (allocated when the packed form was asked for)
-    unsigned            produced = 0;      // ADSB_AMD_OUT_* of the slot's last scan
+    unsigned            produced = 0;      // ADSB_AMD_OUT_* of the slot's last scan: the context's mask when it was SUBMITTED (a repeat after an overflow keeps it)
     uint32_t*          total_d  = nullptr; // device {total, overflow}
     uint32_t*          work_d   = nullptr; // device: one chunk counter per XCD (scan1090_kernel), zero between scans
     uint32_t*          total_h  = nullptr; // pinned {total, overflow}
@@ -78,6 +78,7 @@ struct adsb_amd_ctx
     size_t      staging_cap = 0;
     Slot        slot[2];
     unsigned    outputs = ADSB_AMD_OUT_RECORDS | ADSB_AMD_OUT_DECODED; // arrays the ordering pass produces (adsb_amd_set_outputs)
+    bool        logs_ok = true; // raw records go to per-wave logs (false once a log has overflowed: per-chunk regions from then on)
     std::string error;
 };
 
@@ -117,16 +118,16 @@ void free_slot(Slot& s)
     s.chunks_cap = s.cap_per_chunk = 0;
 }
 
-int ensure_slot(adsb_amd_ctx* c, Slot& s, size_t chunks, size_t cap)
+int ensure_slot(adsb_amd_ctx* c, Slot& s, size_t chunks, size_t cap, unsigned mask)
 {
     if (chunks <= s.chunks_cap && cap == s.cap_per_chunk)
     {
-        if ((c->outputs & ADSB_AMD_OUT_PACKED) && !s.packed) HIP_TRY(c, hipMalloc(&s.packed, s.chunks_cap * s.cap_per_chunk * sizeof(adsb_amd_packed_t)));
+        if ((mask & ADSB_AMD_OUT_PACKED) && !s.packed) HIP_TRY(c, hipMalloc(&s.packed, s.chunks_cap * s.cap_per_chunk * sizeof(adsb_amd_packed_t)));
         return ADSB_AMD_OK;
     }
     free_slot(s);
     size_t nch = chunks ? chunks : 1;
-    HIP_TRY(c, hipMalloc(&s.counts, nch * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&s.counts, 2 * nch * sizeof(uint32_t)));
     s.sums_words = ((nch + kOrderChunks - 1) / kOrderChunks) * kSumStride;
     s.sums_phase = 0;
     HIP_TRY(c, hipMalloc(&s.block_sums, 2 * s.sums_words * sizeof(uint32_t)));
@@ -134,7 +135,7 @@ int ensure_slot(adsb_amd_ctx* c, Slot& s, size_t chunks, size_t cap)
     HIP_TRY(c, hipMalloc(&s.regions, nch * cap * sizeof(adsb_amd_record_t)));
     HIP_TRY(c, hipMalloc(&s.dense, nch * cap * sizeof(adsb_amd_record_t)));
     HIP_TRY(c, hipMalloc(&s.decoded, nch * cap * sizeof(adsb_amd_decoded_t)));
-    if (c->outputs & ADSB_AMD_OUT_PACKED) HIP_TRY(c, hipMalloc(&s.packed, nch * cap * sizeof(adsb_amd_packed_t)));
+    if (mask & ADSB_AMD_OUT_PACKED) HIP_TRY(c, hipMalloc(&s.packed, nch * cap * sizeof(adsb_amd_packed_t)));
     s.chunks_cap    = nch;
     s.cap_per_chunk = cap;
     return ADSB_AMD_OK;
@@ -191,8 +192,16 @@ int make_args(adsb_amd_ctx* c, const void* iq_device, size_t nbytes, size_t buff
 int enqueue(adsb_amd_ctx* c, Slot& s)
 {
     s.args.chunk_records = s.regions;
-    s.args.chunk_counts  = s.counts;
+    s.args.chunk_dir     = s.counts;
     s.args.cap           = (uint32_t)s.cap_per_chunk;
+    // Log mode (scan1090.h): the same memory cut into one log per wave instead of one region per chunk, as long as a record index fits 32
+    // bits and no scan of this context has overflowed a log (then the regions, whose hard bound of two records per position holds for
+    // any input, take over for good: wait_scan).
+    {
+        const uint64_t room = (uint64_t)s.args.total_chunks * s.cap_per_chunk;
+        const uint32_t grid = s.args.total_chunks ? scan_grid(s.args) : 1u;
+        s.args.log_cap      = (c->logs_ok && room < (1ull << 32)) ? (uint32_t)(room / grid) : 0u;
+    }
     s.args.work_counters = s.work_d;
     s.args.block_sums    = s.block_sums + (size_t)s.sums_phase * s.sums_words;
     uint32_t* next_sums  = s.block_sums + (size_t)(s.sums_phase ^ 1) * s.sums_words;
@@ -207,7 +216,6 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     if (c->mode == ADSB_AMD_MODE_2400) HIP_TRY(c, launch_scan2400(s.args, s.total_d, s.stream));
     else HIP_TRY(c, launch_scan1090(s.args, s.total_d, s.stream));
     HIP_TRY(c, hipEventRecord(s.ev_scan1, s.stream));
-    s.produced = c->outputs;
     HIP_TRY(c, launch_order1090(s.args, (s.produced & ADSB_AMD_OUT_RECORDS) ? s.dense : nullptr, (s.produced & ADSB_AMD_OUT_DECODED) ? s.decoded : nullptr,
                                 (s.produced & ADSB_AMD_OUT_PACKED) ? s.packed : nullptr, next_sums, (uint32_t)(s.sums_words / kSumStride), s.total_d, s.stream));
     HIP_TRY(c, hipMemcpyAsync(s.total_h, s.total_d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
@@ -332,8 +340,9 @@ extern "C" int adsb_amd_scan_1090_submit(adsb_amd_ctx_t* c, const void* iq_devic
     if (rc) return rc;
     size_t cap = s.cap_per_chunk ? s.cap_per_chunk : kDefaultCap;
     if (s.cap_hint > cap) cap = s.cap_hint; // the other slot had to grow its regions for this kind of input
-    if ((rc = ensure_slot(c, s, a.total_chunks, cap))) return rc;
-    s.args   = a;
+    if ((rc = ensure_slot(c, s, a.total_chunks, cap, c->outputs))) return rc;
+    s.produced = c->outputs;
+    s.args     = a;
     s.stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
     if ((rc = enqueue(c, s))) return rc;
     s.pending = true;
@@ -352,11 +361,18 @@ int wait_scan(adsb_amd_ctx* c, Slot& s)
     {
         HIP_TRY(c, hipEventSynchronize(s.ev_done));
         if (s.total_h[1] == 0) break;
+        if (s.args.log_cap)
+        { // a wave's log was full (input far denser than the regions were sized for): once more with a region per chunk, same memory
+            c->logs_ok = false;
+            const int rc = enqueue(c, s);
+            if (rc) return rc;
+            continue;
+        }
         size_t cap = s.cap_per_chunk * 8;
         if (cap > (size_t)2 * kChunk) cap = (size_t)2 * kChunk;
         if (cap == s.cap_per_chunk) return fail(c, ADSB_AMD_EHIP, "record overflow at the maximum region size (internal error)");
         const size_t nch  = s.args.total_chunks ? s.args.total_chunks : 1;
-        const size_t per  = 2 * sizeof(adsb_amd_record_t) + sizeof(adsb_amd_decoded_t); // regions + dense + decoded
+        const size_t per  = 2 * sizeof(adsb_amd_record_t) + sizeof(adsb_amd_decoded_t) + ((s.produced & ADSB_AMD_OUT_PACKED) ? sizeof(adsb_amd_packed_t) : 0); // regions + dense + decoded (+ packed)
         const size_t need = nch * cap * per, have = s.chunks_cap * s.cap_per_chunk * per;
         size_t       free_b = 0, total_b = 0;
         HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
@@ -366,7 +382,7 @@ int wait_scan(adsb_amd_ctx* c, Slot& s)
                        std::to_string((free_b + have) >> 20) + " MiB free: split the input into smaller scan calls";
             return ADSB_AMD_ENOMEM;
         }
-        int rc = ensure_slot(c, s, s.args.total_chunks, cap);
+        int rc = ensure_slot(c, s, s.args.total_chunks, cap, s.produced);
         if (rc == ADSB_AMD_OK) rc = enqueue(c, s);
         if (rc) return rc;
         for (Slot& other : c->slot)
@@ -585,6 +601,18 @@ extern "C" int adsb_amd_magnitude_1090(adsb_amd_ctx_t* c, const uint8_t* iq_host
 }
 
 // ------------------------------------------------------------------------------------------------ handler
+namespace
+{
+// the handler's entry points choose the ordering pass's outputs for their own scans and put the caller's choice back when they return
+struct OutputsGuard
+{
+    adsb_amd_ctx* c;
+    unsigned      saved;
+    OutputsGuard(adsb_amd_ctx* ctx, unsigned mask) : c(ctx), saved(ctx->outputs) { c->outputs = mask; }
+    ~OutputsGuard() { c->outputs = saved; }
+};
+} // namespace
+
 struct adsb_amd_handler
 {
     adsb_amd_ctx*                  ctx = nullptr;
@@ -643,7 +671,7 @@ extern "C" long adsb_amd_handler_handle_data(adsb_amd_handler_t* h, const uint8_
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = stage_input(c, iq_host, nbytes);
     if (rc) return rc;
-    c->outputs = h->want_frames ? (ADSB_AMD_OUT_RECORDS | ADSB_AMD_OUT_DECODED) : ADSB_AMD_OUT_PACKED;
+    const OutputsGuard guard(c, h->want_frames ? (ADSB_AMD_OUT_RECORDS | ADSB_AMD_OUT_DECODED) : ADSB_AMD_OUT_PACKED);
     if ((rc = adsb_amd_scan_1090_submit(c, c->staging, nbytes, buffer_bytes, c->stream, 0))) return rc;
     const adsb_amd_record_t*  rec = nullptr;
     const adsb_amd_decoded_t* dec = nullptr;
@@ -783,7 +811,7 @@ extern "C" long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* 
         return 0;
     };
     int rc = 0;
-    c->outputs = h->want_frames ? (ADSB_AMD_OUT_RECORDS | ADSB_AMD_OUT_DECODED) : ADSB_AMD_OUT_PACKED;
+    const OutputsGuard guard(c, h->want_frames ? (ADSB_AMD_OUT_RECORDS | ADSB_AMD_OUT_DECODED) : ADSB_AMD_OUT_PACKED);
     for (size_t b = 0; b < nbatch && !rc; b++)
     {
         {

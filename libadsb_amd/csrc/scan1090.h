@@ -43,9 +43,12 @@ struct ScanArgs
     uint32_t           cpb_magic;    // floor(2^32 / chunks_per_buf) (0xFFFFFFFF for one chunk per buffer): chunk -> (buffer, chunk in buffer) without a division
     uint32_t           total_chunks;
     const uint32_t*    crc_tab;      // 112 entries (ModesChecksumTable semantics)
-    adsb_amd_record_t* chunk_records; // total_chunks * cap
-    uint32_t*          chunk_counts;  // total_chunks
+    adsb_amd_record_t* chunk_records; // total_chunks * cap raw records: one region of `cap` per chunk, or (log_cap != 0) one log of log_cap per wave
+    uint32_t*          chunk_dir;     // two words per chunk: index of its first raw record in chunk_records (log mode), records kept (<= room)
     uint32_t           cap;           // records per chunk region
+    uint32_t           log_cap;       // 0: a chunk's records go to its own region (chunk * cap).  Otherwise every wave appends the records of
+                                      // all its chunks to ONE log of log_cap records (wave w: [w * log_cap, (w + 1) * log_cap)): what the ordering
+                                      // pass reads is then dense (the regions are 64 used bytes per KiB, which costs the pass two thirds of its time)
     uint32_t*          work_counters; // kSubRanges per XCD, counter c at [32 * c] (own cache line each), zero when the scan starts; the ordering pass zeroes them again
     uint32_t           nxcd;          // XCDs of the device (hipDeviceAttributeNumberOfXccs; 8 on MI355X), <= kMaxXcd
     uint32_t           ncu;           // compute units of the device (256 on MI355X)
@@ -66,7 +69,18 @@ inline uint32_t chunks_per_buffer(uint32_t buf_samples)
     return (positions + (uint32_t)kChunk - 1) / (uint32_t)kChunk;
 }
 
-// Demodulation kernel (fills the per-chunk record regions and counts; zeroes `total_and_overflow`).
+// Waves of the persistent scan kernels for this input (both rates): as many single-wave workgroups as the LDS lets the chip hold (16 per
+// CU), in whole (XCD, sub-range) units; fewer for inputs with fewer chunks.
+inline uint32_t scan_grid(const ScanArgs& a)
+{
+    const uint32_t unit = a.nxcd * kSubRanges; // every (XCD, sub-range) gets the same number of waves
+    uint32_t       grid = (a.ncu * 16u / unit) * unit;
+    if (grid == 0) grid = unit;
+    if (grid > a.total_chunks) grid = ((a.total_chunks + unit - 1u) / unit) * unit;
+    return grid;
+}
+
+// Demodulation kernel (fills the raw record regions / logs and the chunk directory; zeroes `total_and_overflow`).
 hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream);
 // Ordering pass: the sorted gather into `dense` (+ field decode).  `total_and_overflow` is a device uint32_t[2]: {number of
 // records in dense, overflow flag}.  a.block_sums holds what the scan accumulated; `next_block_sums` (`next_entries` padded entries, the

@@ -480,6 +480,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
     ChunkGeom g     = chunk_geom_of(a, wr.chunk_of(chunk), kFrameSpan);
     RawWindow raw;
     load_window<kHalo, false, true>(g, lane, raw);
+    uint32_t logged = 0; // records in this wave's log (ScanArgs::log_cap)
 
     for (;;)
     {
@@ -606,10 +607,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         const uint32_t mine = (uint32_t)__builtin_popcountll(surv);
         const uint32_t incl = wave_incl_scan_add(mine);
         const uint32_t n1   = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        Emit           e;
-        e.base  = reinterpret_cast<uint4*>(a.chunk_records + (uint64_t)me * a.cap);
-        e.cap   = a.cap;
-        e.count = 0;
+        Emit           e = begin_chunk(a, me, logged);
         if (ADSB_AMD_PARTS < 3) e.count = (n1 == 0xFFFFFFFFu) ? 1u : 0u; // part builds: keep what was computed alive, emit nothing
         for (uint32_t base = 0; ADSB_AMD_PARTS >= 3 && base < n1; base += (uint32_t)kQueueCap)
         {
@@ -690,7 +688,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
             }
             wave_lds_fence();
         }
-        publish_count(a, me, e.count, lane);
+        publish_count(a, me, e, lane, &logged);
 
         if (next >= end) break;
         chunk = next;
@@ -705,82 +703,106 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
 }
 
 // ---------------------------------------------------------------------------------------------
-// ordering pass: exclusive prefix over the per-chunk counts (two small kernels), then one wave per chunk copies its
-// records into the dense array sorted by (offset, pass).
+// ordering pass: one launch.  A workgroup takes 256 consecutive chunks: exclusive prefix over their record counts (the records of
+// all earlier workgroups come from block_sums, which the scan kernels accumulated chunk by chunk), then ONE LANE PER RECORD moves the
+// records into the dense arrays sorted by (offset, pass).
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kOrderBlock = 256; // chunks per workgroup of the ordering pass
-
-// inclusive scan over a 256-thread workgroup (4 waves); *block_total receives the sum
-__device__ __forceinline__ uint32_t block_incl_scan_256(uint32_t v, uint32_t* wave_tot /* [4] shared */, uint32_t* block_total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t  x    = wave_incl_scan_add(v);
-    if (lane == 63) wave_tot[wave] = x;
-    __syncthreads();
-    uint32_t basev = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++)
-    {
-        const uint32_t t = wave_tot[w];
-        if (w < wave) basev += t;
-        tot += t;
-    }
-    *block_total = tot;
-    __syncthreads();
-    return x + basev;
-}
+constexpr uint32_t kOrderBlock   = 256;  // chunks per workgroup of the ordering pass
+#ifndef ADSB_AMD_ORDER_THREADS
+#define ADSB_AMD_ORDER_THREADS 640
+#endif
+constexpr uint32_t kOrderThreads = ADSB_AMD_ORDER_THREADS; // its threads = records it moves per trip (a block of a quiet band holds ~550); two workgroups per CU
+static_assert(kOrderThreads % 64 == 0 && kOrderThreads >= kOrderBlock && kOrderThreads <= 1024, "whole waves, at least the chunk threads");
 
 // reverse the bit order inside each byte: message bit n (n = 8k + b, b = 0 first/MSB) -> bit 7-b of byte k
 __device__ __forceinline__ uint32_t msg_bytes(uint32_t bits) { return __builtin_bswap32(__builtin_bitreverse32(bits)); }
 
-// One workgroup per 256 chunks, one thread per chunk: position of the chunk's records in the dense array = records of all
-// earlier blocks (summed here from block_sums, which the scan kernel accumulated chunk by chunk: a separate summing kernel cost
-// 4 us and a launch gap per step) + exclusive prefix inside the block; then the thread copies its chunk's
-// few records in (offset, pass) order, turning each raw record into the public adsb_amd_record_t (repair flip, byte
-// order, address).
-__global__ __launch_bounds__(256) void gather_sorted_kernel(const adsb_amd_record_t* __restrict__ chunk_records,
-                                                            const uint32_t* __restrict__ counts, const uint32_t* __restrict__ block_sums,
-                                                            uint32_t nchunks, uint32_t nblocks, uint32_t cap, uint32_t chunks_per_buf,
+// Round 4.  Until then a thread walked its chunk's records one after the other -- load the record, count the chunk's smaller keys, decode,
+// store, next -- and a wave took as long as its longest chunk: seven dependent trips of a memory round trip each where the average chunk
+// has two records, 28-31 us for 18 MB.  Now the chunk threads only publish where their records start (LDS), every record gets a lane of
+// its own (`owner`: which chunk a record of the block belongs to, scattered by the chunk threads), the lane fetches its record and, in
+// the same breath, the keys of the chunk's other records (four at a time), and the whole block is done after one round trip.
+__global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb_amd_record_t* __restrict__ chunk_records,
+                                                            const uint32_t* __restrict__ chunk_dir, const uint32_t* __restrict__ block_sums,
+                                                            uint32_t nchunks, uint32_t nblocks, uint32_t cap, uint32_t log_cap, uint32_t chunks_per_buf,
                                                             adsb_amd_record_t* __restrict__ dense, adsb_amd_decoded_t* __restrict__ decoded,
                                                             adsb_amd_packed_t* __restrict__ packed, uint32_t* __restrict__ total_overflow,
                                                             uint32_t* __restrict__ next_block_sums,
                                                             uint32_t next_entries, uint32_t* __restrict__ work_counters)
 {
-    __shared__ uint32_t wave_tot[4];
+    constexpr uint32_t kWaves = kOrderThreads / 64;
+    __shared__ uint32_t before_w[kWaves], count_w[kOrderBlock / 64];
+    __shared__ uint32_t cstart[kOrderBlock + 1]; // first record of each chunk among the block's records, and their total
+    __shared__ uint32_t csrc[kOrderBlock];       // log mode: index of the chunk's first raw record
+    __shared__ uint8_t  owner[kOrderThreads];    // chunk (within the block) of record `trip base + t`
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // housekeeping for the next scan of this slot: its block sums (the other of two arrays, all of it: the next input may be larger
     // than this one) and the work counters start from zero
-    for (uint32_t k = blockIdx.x * kOrderBlock + threadIdx.x; k < 2u * next_entries; k += nblocks * kOrderBlock)
+    for (uint32_t k = blockIdx.x * kOrderThreads + tid; k < 2u * next_entries; k += nblocks * kOrderThreads)
         next_block_sums[(k >> 1) * kSumStride + (k & 1u)] = 0;
-    if (blockIdx.x == 0 && threadIdx.x < kWorkCounters) work_counters[threadIdx.x * 32u] = 0;
-    if (threadIdx.x == 0 && block_sums[blockIdx.x * kSumStride + 1]) atomicOr(&total_overflow[1], 1u); // some chunk of this block overflowed its region
-    // records in earlier blocks
+    if (blockIdx.x == 0 && tid < kWorkCounters) work_counters[tid * 32u] = 0;
+    if (tid == 0 && block_sums[blockIdx.x * kSumStride + 1]) atomicOr(&total_overflow[1], 1u); // some chunk of this block overflowed its region
+    // records in earlier blocks, and this block's chunk counts
     uint32_t before = 0;
-    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kOrderBlock) before += block_sums[b * kSumStride];
-    uint32_t base;
-    (void)block_incl_scan_256(before, wave_tot, &base);
-
-    const uint32_t c = blockIdx.x * kOrderBlock + threadIdx.x;
-    uint32_t       n = (c < nchunks) ? counts[c] : 0u;
-    if (n > cap) n = cap;
-    uint32_t       tot;
-    const uint32_t incl = block_incl_scan_256(n, wave_tot, &tot);
-    if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) total_overflow[0] = base + tot;
-    if (n == 0) return;
-
-    const uint4*       src    = reinterpret_cast<const uint4*>(chunk_records + (uint64_t)c * cap);
-    adsb_amd_record_t* dst    = dense ? dense + (base + incl - n) : nullptr;
-    const uint32_t     buffer = c / chunks_per_buf;
-    for (uint32_t i = 0; i < n; i++)
+    for (uint32_t b = tid; b < blockIdx.x; b += kOrderThreads) before += block_sums[b * kSumStride];
+    const uint32_t c  = blockIdx.x * kOrderBlock + tid;
+    const uint2    de = (tid < kOrderBlock && c < nchunks) ? *reinterpret_cast<const uint2*>(chunk_dir + 2ull * c) : make_uint2(0u, 0u); // {first raw record (log mode), records kept}
+    const uint32_t n  = de.y;
+    before            = wave_incl_scan_add(before);
+    if (lane == 63) before_w[wave] = before;
+    uint32_t incl = 0;
+    if (tid < kOrderBlock)
+    { // (whole waves: kOrderBlock is a multiple of 64)
+        incl = wave_incl_scan_add(n);
+        if (lane == 63) count_w[wave] = incl;
+    }
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kWaves; w++) base += before_w[w];
+    uint32_t tot = 0, mine = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kOrderBlock / 64; w++)
     {
-        const uint4    lo   = src[2 * i];
-        uint4          hi   = src[2 * i + 1];
-        const uint32_t key  = (lo.x << 1) | ((lo.y >> 16) & 1u); // (offset, pass)
+        const uint32_t t = count_w[w];
+        if (w < wave) mine += t;
+        tot += t;
+    }
+    const uint32_t excl = incl - n + mine;
+    if (tid < kOrderBlock)
+    {
+        cstart[tid] = excl;
+        csrc[tid]   = de.x;
+    }
+    if (tid == 0) cstart[kOrderBlock] = tot;
+    if (blockIdx.x == nblocks - 1 && tid == 0) total_overflow[0] = base + tot;
+
+    for (uint32_t trip = 0; trip < tot; trip += kOrderThreads)
+    {
+        if (trip) __syncthreads(); // the previous trip's readers of `owner` are done
+        if (tid < kOrderBlock)
+            for (uint32_t i = (excl < trip ? trip - excl : 0u); i < n && excl + i < trip + kOrderThreads; i++) owner[excl + i - trip] = (uint8_t)tid;
+        __syncthreads();
+        const uint32_t r = trip + tid; // this lane's record among the block's
+        if (r >= tot) continue;
+        const uint32_t cc = owner[tid], first = cstart[cc], nn = cstart[cc + 1] - first, i = r - first;
+        const uint32_t ch = blockIdx.x * kOrderBlock + cc; // the chunk
+        const uint4*   src = reinterpret_cast<const uint4*>(chunk_records + (log_cap ? (uint64_t)csrc[cc] : (uint64_t)ch * cap));
+        const uint4    lo  = src[2 * i];
+        uint4          hi  = src[2 * i + 1];
+        // rank among the chunk's records by (offset, pass): their keys four at a time (a chunk seldom has more)
+        const uint32_t key = (lo.x << 1) | ((lo.y >> 16) & 1u);
         uint32_t       rank = 0;
-        for (uint32_t k = 0; k < n; k++)
+        for (uint32_t k0 = 0; k0 < nn; k0 += 4)
         {
-            const uint4 q = src[2 * k];
-            rank += (((q.x << 1) | ((q.y >> 16) & 1u)) < key) ? 1u : 0u;
+            uint2 q[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) q[k] = *reinterpret_cast<const uint2*>(&src[2 * (k0 + k < nn ? k0 + k : i)]);
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) rank += (((q[k].x << 1) | ((q[k].y >> 16) & 1u)) < key) ? 1u : 0u;
         }
+        const uint32_t buffer = ch / chunks_per_buf;
+        const size_t   out    = (size_t)base + first + rank;
         // raw -> adsb_amd_record_t: apply the 1-bit repair, order the bytes, pull the address out
         const uint32_t df = lo.y & 0xFFu, nbits = (lo.y >> 8) & 0xFFu, flags = (lo.y >> 16) & 0xFFu;
         const int      errorbit = (int)(lo.y >> 24) - 1;
@@ -805,7 +827,7 @@ __global__ __launch_bounds__(256) void gather_sorted_kernel(const adsb_amd_recor
         o1.w = (m2 >> 16) | (m3 << 16);
         if (dense)
         {
-            uint4* o = reinterpret_cast<uint4*>(dst + rank);
+            uint4* o = reinterpret_cast<uint4*>(dense + out);
             o[0]     = o0;
             o[1]     = o1;
         }
@@ -817,11 +839,11 @@ __global__ __launch_bounds__(256) void gather_sorted_kernel(const adsb_amd_recor
         g[12] = (uint8_t)m3; g[13] = (uint8_t)(m3 >> 8);
         const adsb_amd_decoded_t d = decode_record(g, (int)df);
         if (decoded)
-            *reinterpret_cast<uint4*>(decoded + (base + incl - n) + rank) =
+            *reinterpret_cast<uint4*>(decoded + out) =
                 make_uint4((uint32_t)d.kind | ((uint32_t)d.metype << 8) | ((uint32_t)d.mesub << 16) | ((uint32_t)d.odd << 24), (uint32_t)d.altitude, d.a, d.b);
         if (packed)
         { // the record's first sixteen bytes, then df, flags, kind, odd and the decoded values (adsb_amd_packed_t)
-            uint4* o = reinterpret_cast<uint4*>(packed + (base + incl - n) + rank);
+            uint4* o = reinterpret_cast<uint4*>(packed + out);
             o[0]     = o0;
             o[1]     = make_uint4(df | (flags << 8) | ((uint32_t)d.kind << 16) | ((uint32_t)d.odd << 24), (uint32_t)d.altitude, d.a, d.b);
         }
@@ -871,12 +893,7 @@ hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipS
 {
     if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
     // persistent single-wave workgroups: enough to fill every CU at the LDS-limited occupancy (16 per CU)
-#ifndef ADSB_AMD_WAVES_PER_CU
-#define ADSB_AMD_WAVES_PER_CU 16
-#endif
-    const uint32_t unit = a.nxcd * kSubRanges; // the grid is a multiple of this: every (XCD, sub-range) gets the same number of waves
-    uint32_t       grid = (a.ncu * ADSB_AMD_WAVES_PER_CU / unit) * unit;
-    if (grid > a.total_chunks) grid = ((a.total_chunks + unit - 1u) / unit) * unit;
+    const uint32_t grid = scan_grid(a);
     hipLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
     return hipGetLastError();
 }
@@ -894,8 +911,8 @@ hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, adsb_am
     if (a.total_chunks == 0) return hipSuccess;
     static_assert(kOrderBlock == kOrderChunks, "one block-sum entry per workgroup of the ordering pass");
     const uint32_t nblocks = (a.total_chunks + kOrderBlock - 1u) / kOrderBlock;
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderBlock), 0, stream, a.chunk_records, a.chunk_counts, a.block_sums,
-                       a.total_chunks, nblocks, a.cap, a.chunks_per_buf, dense, decoded, packed, total_and_overflow, next_block_sums, next_entries, a.work_counters);
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderThreads), 0, stream, a.chunk_records, a.chunk_dir, a.block_sums,
+                       a.total_chunks, nblocks, a.cap, a.log_cap, a.chunks_per_buf, dense, decoded, packed, total_and_overflow, next_block_sums, next_entries, a.work_counters);
     return hipGetLastError();
 }
 

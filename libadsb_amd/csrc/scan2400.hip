@@ -240,6 +240,7 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     ChunkGeom g     = chunk_geom_of(a, wr.chunk_of(chunk), kSpan24);
     RawWindow raw;
     load_window<kHalo24>(g, lane, raw);
+    uint32_t logged = 0; // records in this wave's log (ScanArgs::log_cap)
 
     for (;;)
     {
@@ -336,7 +337,11 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
 
     // ---------------- candidates -> queue -> demodulation, kQueue24 per pass
 #if defined(ADSB_AMD_PARTS24) && ADSB_AMD_PARTS24 == 1
-    publish_count(a, me, (surv == 0x123456789ull) ? 1 : 0, lane); // keeps the gate alive
+    {
+        Emit e  = begin_chunk(a, me, logged);
+        e.count = (surv == 0x123456789ull) ? 1 : 0; // keeps the gate alive
+        publish_count(a, me, e, lane, &logged);
+    }
     if (next >= wr.end) break;
     chunk = next;
     next  = ahead;
@@ -346,10 +351,7 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     const uint32_t mine = (uint32_t)__builtin_popcountll(surv);
     const uint32_t incl = wave_incl_scan_add(mine);
     const uint32_t n1   = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    Emit           e;
-    e.base  = reinterpret_cast<uint4*>(a.chunk_records + (uint64_t)me * a.cap);
-    e.cap   = a.cap;
-    e.count = 0;
+    Emit           e = begin_chunk(a, me, logged);
     // A pass takes whole lanes (a lane's survivors of one 8-position group are consecutive queue entries in ascending position, so
     // a run never straddles two passes) until kQueue24 entries are full.
     const uint32_t excl = incl - mine;
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
         wave_lds_fence();
         base = next_base;
     }
-    publish_count(a, me, e.count, lane);
+    publish_count(a, me, e, lane, &logged);
 
     if (next >= wr.end) break;
     chunk = next;
@@ -480,9 +482,7 @@ hipError_t launch_scan2400(const ScanArgs& a, uint32_t* total_and_overflow, hipS
 {
     if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
     // persistent single-wave workgroups, as many as the LDS lets a CU hold (16 x 10 208 bytes), in whole (XCD, sub-range) units
-    const uint32_t unit = a.nxcd * kSubRanges;
-    uint32_t       grid = (a.ncu * 16u / unit) * unit;
-    if (grid > a.total_chunks) grid = ((a.total_chunks + unit - 1u) / unit) * unit;
+    const uint32_t grid = scan_grid(a);
     hipLaunchKernelGGL(scan2400_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
     return hipGetLastError();
 }

@@ -229,9 +229,10 @@ __device__ __forceinline__ LaneTables load_lane_tables(const uint32_t* __restric
 
 struct Emit
 {
-    uint4*   base; // this chunk's region, one raw record = 2 x uint4
-    uint32_t cap;
+    uint4*   base;  // where this chunk's records go, one raw record = 2 x uint4
+    uint32_t cap;   // room there
     uint32_t count; // wave-uniform
+    uint32_t start; // index of the first of them in ScanArgs::chunk_records (log mode)
 };
 
 // A raw record is what the wave has in scalar registers anyway; turning it into the public adsb_amd_record_t (byte
@@ -403,16 +404,39 @@ __device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWin
 // A finished chunk: its record count for the ordering pass, and the count (clamped to the region size) added to the sum of its group
 // of kOrderChunks chunks -- the ordering pass starts from finished sums instead of running a summing kernel first.  The atomics need
 // no reply; each sum sits on its own cache line (256 additions per line over the whole scan).
-__device__ __forceinline__ void publish_count(const ScanArgs& a, uint32_t chunk, uint32_t count, int lane)
+// Where the records of chunk `me` go: its own region, or (log mode) the next free entry of this wave's log; `logged` = records the wave
+// has in its log so far.  Everything is wave-uniform.
+__device__ __forceinline__ Emit begin_chunk(const ScanArgs& a, uint32_t me, uint32_t logged)
 {
+    Emit e;
+    e.count = 0;
+    if (a.log_cap)
+    {
+        e.start = blockIdx.x * a.log_cap + logged;
+        e.cap   = a.log_cap - logged;
+        e.base  = reinterpret_cast<uint4*>(a.chunk_records + e.start);
+    }
+    else
+    {
+        e.start = 0; // the ordering pass computes chunk * cap itself (64 bits)
+        e.cap   = a.cap;
+        e.base  = reinterpret_cast<uint4*>(a.chunk_records + (uint64_t)me * a.cap);
+    }
+    return e;
+}
+
+__device__ __forceinline__ void publish_count(const ScanArgs& a, uint32_t chunk, const Emit& e, int lane, uint32_t* logged)
+{
+    const uint32_t count = e.count, kept = count < e.cap ? count : e.cap;
+    *logged += kept;
     // Vector atomics, one lane: they are performed where all XCDs see them.  The scalar unit's atomics (s_atomic_add) would save the six
     // vector instructions this costs, but they act on the issuing XCD's L2 only -- tools/isa_probe.hip loses additions from different XCDs
     // to one word -- and a group of kOrderChunks chunks may straddle two XCD ranges.
     if (lane != 0) return;
-    a.chunk_counts[chunk] = count;
-    uint32_t* sum         = a.block_sums + (chunk / kOrderChunks) * kSumStride;
-    if (count) atomicAdd(sum, count < a.cap ? count : a.cap);
-    if (count > a.cap) atomicOr(sum + 1, 1u);
+    *reinterpret_cast<uint2*>(a.chunk_dir + 2ull * chunk) = make_uint2(e.start, kept);
+    uint32_t* sum = a.block_sums + (chunk / kOrderChunks) * kSumStride;
+    if (count) atomicAdd(sum, kept);
+    if (count > e.cap) atomicOr(sum + 1, 1u);
 }
 
 // Chunk order.  Workgroups b and b + nxcd share an XCD (round-robin dispatch).  The chunks are dealt out in groups of 16

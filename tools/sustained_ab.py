@@ -12,17 +12,22 @@ iq, _ = synth.fill_range(0, 4096, nthreads=16)
 d = torch.from_numpy(iq).cuda(); torch.cuda.synchronize()
 st = torch.cuda.current_stream().cuda_stream
 scanners = []
+PACKED = os.environ.get("AB_PACKED", "1") == "1"  # what bench.py moves: the packed form
+def fetch(sc, slot):
+    return sc.fetch_packed(slot, copy=False) if PACKED else sc.fetch_decoded(slot, copy=False)
 for path in sys.argv[1:]:
     A._lib = None; A.LIB_PATH = os.path.abspath(path)
-    scanners.append((path, A.Scanner(0)))
+    sc = A.Scanner(0)
+    if PACKED: sc.set_outputs(A.OUT_PACKED)
+    scanners.append((path, sc))
 for rnd in range(2):
     for path, sc in scanners:
-        t0 = time.perf_counter(); ks = []
+        t0 = time.perf_counter(); ks = []; ts = []
         sc.submit(d.data_ptr(), d.numel(), BB, st, 0); i = 1
         while time.perf_counter() - t0 < secs:
             sc.submit(d.data_ptr(), d.numel(), BB, st, i & 1)
-            sc.fetch_decoded((i - 1) & 1, copy=False); ks.append(sc.timing((i - 1) & 1)[0]); i += 1
-        sc.fetch_decoded((i - 1) & 1, copy=False)
+            fetch(sc, (i - 1) & 1); tm = sc.timing((i - 1) & 1); ks.append(tm[0]); ts.append(tm[1]); i += 1
+        fetch(sc, (i - 1) & 1)
         el = time.perf_counter() - t0
-        print("%-22s round %d: kernel ms median (second half) %.4f  step %.4f ms" % (os.path.basename(path), rnd, statistics.median(ks[len(ks) // 2:]), el / i * 1e3), flush=True)
+        print("%-22s round %d: kernel ms median (second half) %.4f  scan start -> count on the host %.4f  step %.4f ms" % (os.path.basename(path), rnd, statistics.median(ks[len(ks) // 2:]), statistics.median(ts[len(ts) // 2:]), el / i * 1e3), flush=True)
         time.sleep(0.3)
