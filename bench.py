@@ -61,6 +61,7 @@ def parse_args(argv=None):
                     "(parity-green, the headline).  24: the library's own 2.4 MS/s mode (ADSB_AMD_MODE_2400) on the same pulse trains sampled at "
                     "2.4 MS/s -- BASELINE.json quotes that rate, nothing in the reference demodulates it (SURVEY.md F3/F5): parity unpinned, "
                     "the kernel is checked against its specification oracle/oracle2400.c")
+    ap.add_argument("--time-every", type=int, default=4, help="HIP events around the scan kernel on every n-th launch of the timed region (1: all)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the end_to_end and uat978 blocks (profiling runs)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N > 1 ranks all on cuda:0 with the gloo backend: exercises the "
                     "multi-rank code path (sharding, record gather, resolve) on a one-GPU box; the numbers mean nothing")
@@ -224,28 +225,31 @@ def make_runner(args, sc, d_iq, BB, stream):
 
     def run(steps):
         """`steps` pipelined steps, each delivering the sorted records with their decoded fields to the host in the packed hand-over
-        form (adsb_amd_packed_t: 32 bytes a record); returns (packed records of the last step, sum of scan-kernel ms, sum of
-        enqueue-to-count ms)."""
-        k_ms = t_ms = 0.0
+        form (adsb_amd_packed_t: 32 bytes a record); returns (packed records of the last step, sum of scan-kernel ms over the steps
+        that carried timing events, how many did, sum of scan-start-to-count ms over the same steps)."""
+        acc = [0.0, 0, 0.0]
         rec = None
+
+        def note(slot):
+            tm = sc.timing_if_timed(slot)
+            if tm is not None:
+                acc[0] += tm[0]
+                acc[1] += 1
+                acc[2] += tm[1]
         if args.serial:
             for i in range(steps):
                 sc.submit(d_iq.data_ptr(), nbytes, BB, stream, 0)
                 rec = sc.fetch_packed(0, copy=False)
-                a, b = sc.timing(0)
-                k_ms += a
-                t_ms += b
-            return rec, k_ms, t_ms
+                note(0)
+            return rec, acc[0], acc[1], acc[2]
         sc.submit(d_iq.data_ptr(), nbytes, BB, stream, 0)
         for i in range(1, steps):
             sc.submit(d_iq.data_ptr(), nbytes, BB, stream, i & 1)
             rec = sc.fetch_packed((i - 1) & 1, copy=False)
-            a, b = sc.timing((i - 1) & 1)
-            k_ms += a
-            t_ms += b
+            note((i - 1) & 1)
         rec = sc.fetch_packed((steps - 1) & 1, copy=False)
-        a, b = sc.timing((steps - 1) & 1)
-        return rec, k_ms + a, t_ms + b
+        note((steps - 1) & 1)
+        return rec, acc[0], acc[1], acc[2]
     return run
 
 
@@ -269,19 +273,26 @@ def bench_1090_single(args, local_rank, A, synth, torch):
     # Set-up, not measurement: the first scans fault in the record regions (512 MiB of address space, touched where
     # used) and the clocks ramp up from idle; both are one-off costs of a long-running demodulator.  SETUP_STEPS untimed
     # steps absorb them before the W warm-up steps the caller asked for (reported as "setup_steps").
-    run(SETUP_STEPS)
+    sc.set_timing(1)
+    _, k100, n100, _ = run(100)  # the first 100 of them with events on every scan: reported as kernel_ms_first_100
+    run(SETUP_STEPS - 100)
+    # In the timed region the two HIP events that take the scan kernel's start and end ride on every --time-every-th launch (they cost the
+    # stream ~4 us per launch that carries them: profiles/r04_step_timeline.txt); kernel_ms is the mean over those launches.
+    sc.set_timing(args.time_every)
     if args.warmup > 0:
         run(args.warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rec, k_ms, t_ms = run(args.steps)
+    rec, k_ms, k_n, t_ms = run(args.steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if k_n == 0:
+        raise SystemExit("--time-every %d leaves no timed launch among %d steps" % (args.time_every, args.steps))
     nrec = int(len(rec))
     rec = rec.view(np.uint8).copy().view(rec.dtype)  # a byte copy (numpy copies a structured array field by field)
 
     samples = nbytes // 2
-    kernel_ms = k_ms / args.steps
+    kernel_ms = k_ms / k_n
     alg_bytes = 2.0 * samples + 32.0 * nrec
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     # host half on the records of one step: accepted frames -> msgs/s (no listener; with a native counting listener: end_to_end)
@@ -310,6 +321,9 @@ def bench_1090_single(args, local_rank, A, synth, torch):
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(nbytes if args.rate == 20 else "mode2400:%d" % nbytes),
                      "kernel": "scan1090_kernel" if args.rate == 20 else "scan2400_kernel", "kernel_ms": round(kernel_ms, 4),
+                     "kernel_ms_source": "HIP events on the kernel's dispatch (hipExtLaunchKernelGGL start/stop events, the stream the scan is launched on), "
+                                         "%d of the %d timed launches (every %s)" % (k_n, args.steps, args.time_every),
+                     "kernel_ms_first_100": round(k100 / max(1, n100), 4),
                      "algorithmic_bytes": int(alg_bytes)},
         "records_per_step": nrec, "frames_injected": injected,
         "decoded_msgs_per_step_rank0": int(accepted),
@@ -318,7 +332,7 @@ def bench_1090_single(args, local_rank, A, synth, torch):
         # two sustains the slower of the two rates (the host's)
         "decoded_msgs_per_s": round(min(accepted * args.steps / elapsed, accepted / max(resolve_s, 1e-9)), 1),
         "decoded_msgs_per_s_gpu_side": round(accepted * args.steps / elapsed, 1),
-        "gpu_enqueue_to_count_ms": round(t_ms / args.steps, 4),
+        "gpu_enqueue_to_count_ms": round(t_ms / k_n, 4),
         "host_resolve_ms_rank0": round(resolve_s * 1e3, 2),
         "host_resolve_note": "records + GPU-decoded fields -> ICAO gating, skip-ahead (helper thread) | batched CPR, aircraft update (calling thread), no listener; best of 5 stretches",
     }
@@ -330,13 +344,15 @@ def bench_1090_single(args, local_rank, A, synth, torch):
             d24 = torch.from_numpy(iq24).cuda()
             sc24 = A.Scanner(local_rank, mode=A.MODE_2400)
             sc24.set_outputs(A.OUT_PACKED)
+            sc24.set_timing(args.time_every)
             run24 = make_runner(args, sc24, d24, BB, stream)
             run24(SETUP_STEPS)  # the GPU sat idle while the host generated this input: the same untimed set-up scans as the headline (see SETUP_STEPS)
             torch.cuda.synchronize()
             t24 = time.perf_counter()
-            r24, k24, _ = run24(50)
+            r24, k24, n24, _ = run24(50)
             torch.cuda.synchronize()
             e24 = time.perf_counter() - t24
+            k24 = k24 / n24 * 50  # (mean over the launches that carried events) x the 50 steps
             r24 = r24.view(np.uint8).copy().view(r24.dtype)
             res24 = A.Resolver(mode=A.MODE_2400, sample_clock_hz=2400000)
             acc24, _, _ = res24.feed(r24, BB // 2, nbuf, collect=False)

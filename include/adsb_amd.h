@@ -186,12 +186,17 @@ int adsb_amd_scan_1090_fetch_packed(adsb_amd_ctx_t* ctx, int slot, const adsb_am
  * HIP-registered host memory) on `hip_stream` (NULL: an internal stream, and the call returns after the copy has completed): for the
  * hand-over of the sharded recorded-file case -- an RCCL gather of the records from device buffers, or every
  * GPU writing into its segment of node-shared host memory (libadsb_amd/shard.py).  ADSB_AMD_ENOSPC when cap is too
- * small (*n holds the count) or when a chunk region overflowed (use adsb_amd_scan_1090_fetch, which repeats the scan). */
+ * small (*n holds the count).  Like every fetch it repeats the scan with more room when the raw-record area overflowed. */
 int adsb_amd_scan_1090_fetch_device(adsb_amd_ctx_t* ctx, int slot, void* dst_device, size_t cap, void* hip_stream, size_t* n);
 /* the same for the packed form (needs ADSB_AMD_OUT_PACKED; an entry is as large as a record) */
 int adsb_amd_scan_1090_fetch_device_packed(adsb_amd_ctx_t* ctx, int slot, void* dst_device, size_t cap, void* hip_stream, size_t* n);
-/* Device time of the last completed scan on `slot`: the demodulation kernel alone, and submit-to-records-on-host. */
+/* Device time of the last completed scan on `slot`: the demodulation kernel alone (HIP events around its launch, on the stream it was
+ * submitted to), and scan start to record count on the host.  ADSB_AMD_ESTATE when that scan was not timed (adsb_amd_set_timing). */
 int adsb_amd_scan_1090_timing(adsb_amd_ctx_t* ctx, int slot, float* scan_kernel_ms, float* total_ms);
+/* Which scans get the two timing events around the demodulation kernel: every `every`-th submit of the context (1, the default:
+ * all; 0: none).  An event costs the scan's stream 3-5 us, two of them 3 % of a 1 GiB scan: a caller that pipelines scans back to back
+ * and wants the kernel time as a running figure samples it. */
+int adsb_amd_set_timing(adsb_amd_ctx_t* ctx, unsigned every);
 
 /* Parity helper: magnitudes exactly as ADSB1090.cpp:165-173 computes them (n = nbytes/2 values). */
 int adsb_amd_magnitude_1090(adsb_amd_ctx_t* ctx, const uint8_t* iq_host, size_t nbytes, uint16_t* mag_out);

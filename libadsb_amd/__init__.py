@@ -34,7 +34,7 @@ ON_CHANGED = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
 
 EXPORTS = [
     "adsb_amd_version", "adsb_amd_create", "adsb_amd_create_mode", "adsb_amd_handler_create_mode", "adsb_amd_resolver_set_mode", "adsb_amd_destroy", "adsb_amd_last_error", "adsb_amd_scan_1090",
-    "adsb_amd_scan_1090_submit", "adsb_amd_scan_1090_fetch", "adsb_amd_scan_1090_fetch_decoded", "adsb_amd_scan_1090_fetch_packed", "adsb_amd_set_outputs", "adsb_amd_resolver_feed_packed", "adsb_amd_handler_set_frames", "adsb_amd_scan_1090_fetch_device", "adsb_amd_scan_1090_fetch_device_packed", "adsb_amd_scan_1090_timing", "adsb_amd_magnitude_1090",
+    "adsb_amd_scan_1090_submit", "adsb_amd_scan_1090_fetch", "adsb_amd_scan_1090_fetch_decoded", "adsb_amd_scan_1090_fetch_packed", "adsb_amd_set_outputs", "adsb_amd_resolver_feed_packed", "adsb_amd_handler_set_frames", "adsb_amd_scan_1090_fetch_device", "adsb_amd_scan_1090_fetch_device_packed", "adsb_amd_scan_1090_timing", "adsb_amd_set_timing", "adsb_amd_magnitude_1090",
     "adsb_amd_decode_1090", "adsb_amd_decode_record_host", "adsb_amd_resolver_feed_decoded", "adsb_amd_cpr_nl", "adsb_amd_cpr_global", "adsb_amd_cpr_global_batch",
     "adsb_amd_resolver_create", "adsb_amd_resolver_destroy", "adsb_amd_resolver_set_sample_clock", "adsb_amd_resolver_feed",
     "adsb_amd_resolver_aircraft_count", "adsb_amd_count_callback", "adsb_amd_handler_create", "adsb_amd_handler_destroy", "adsb_amd_handler_last_error",
@@ -99,6 +99,8 @@ def lib():
         L.adsb_amd_resolver_feed_decoded.restype = C.c_long
         L.adsb_amd_scan_1090_fetch_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
         L.adsb_amd_scan_1090_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        if hasattr(L, "adsb_amd_set_timing"):  # absent from the older builds tools/ab.py compares against (the export test covers the product)
+            L.adsb_amd_set_timing.argtypes = [C.c_void_p, C.c_uint]
         L.adsb_amd_magnitude_1090.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.adsb_amd_resolver_create.restype = C.c_void_p
         L.adsb_amd_resolver_destroy.argtypes = [C.c_void_p]
@@ -264,6 +266,17 @@ class Scanner:
     def timing(self, slot=0):
         a, b = C.c_float(), C.c_float()
         self._check(self._l.adsb_amd_scan_1090_timing(self._h, slot, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_timing(self, every):
+        """HIP events around the demodulation kernel of every `every`-th submit (1: all, the default; 0: none)."""
+        self._check(self._l.adsb_amd_set_timing(self._h, every))
+
+    def timing_if_timed(self, slot=0):
+        """(kernel ms, scan start -> count on the host ms) of the slot's last scan, or None when that scan carried no timing events."""
+        a, b = C.c_float(), C.c_float()
+        if self._l.adsb_amd_scan_1090_timing(self._h, slot, C.byref(a), C.byref(b)) != 0:
+            return None
         return a.value, b.value
 
     def magnitude(self, iq):

@@ -48,7 +48,8 @@ struct Slot
     unsigned            produced = 0;      // ADSB_AMD_OUT_* of the slot's last scan: the context's mask when it was SUBMITTED (a repeat after an overflow keeps it)
     uint32_t*          total_d  = nullptr; // device {total, overflow}
     uint32_t*          work_d   = nullptr; // device: one chunk counter per XCD (scan1090_kernel), zero between scans
-    uint32_t*          total_h  = nullptr; // pinned {total, overflow}
+    unsigned long long* total_h = nullptr; // page-locked: {total, overflow} as two words (copied), or count | (stamp << 1 | overflow) << 32 (kCountHost)
+    unsigned long long* total_h_dev = nullptr; // the device's address of it
     adsb_amd_record_t* host     = nullptr; // pinned result
     adsb_amd_decoded_t* host_dec = nullptr; // pinned, parallel to host (same capacity)
     adsb_amd_packed_t*  host_packed = nullptr; // pinned, same capacity
@@ -56,12 +57,15 @@ struct Slot
     size_t             host_cap = 0;       // records
     size_t             chunks_cap = 0, cap_per_chunk = 0;
     size_t             cap_hint = 0;       // region size the other slot had to grow to: this slot's next scan starts with it
-    hipEvent_t         ev_scan0 = nullptr, ev_scan1 = nullptr, ev_done = nullptr;
+    hipEvent_t         ev_scan0 = nullptr, ev_scan1 = nullptr, ev_order = nullptr, ev_done = nullptr;
+    uint32_t           seq = 0;            // launches of this slot: the stamp the ordering pass writes beside the count (kCountHost)
     bool               pending = false, timed = false;
+    bool               events = false;     // this scan has the two timing events around its kernel
     // the submitted job (needed again when a chunk region overflows and the scan is repeated with a larger cap)
     ScanArgs    args{};
     hipStream_t stream   = nullptr;
     size_t      nrecords = 0;
+    bool        overflow = false;
     float       scan_ms = 0.f, total_ms = 0.f;
 };
 } // namespace
@@ -71,13 +75,19 @@ struct adsb_amd_ctx
     int         device = 0;
     int         mode   = ADSB_AMD_MODE_2000;
     uint32_t    nxcd = 8, ncu = 256; // topology of the device, read once at create
-    hipStream_t stream = nullptr, copy_stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr, ctl_stream = nullptr;
     uint32_t*   crc_tab = nullptr;
     uint16_t*   lut978  = nullptr;
     uint8_t*    staging = nullptr; // device copy of host input
     size_t      staging_cap = 0;
     Slot        slot[2];
     unsigned    outputs = ADSB_AMD_OUT_RECORDS | ADSB_AMD_OUT_DECODED; // arrays the ordering pass produces (adsb_amd_set_outputs)
+    unsigned    timing_every = 1, submits = 0; // adsb_amd_set_timing
+    int         count_path = 0;                // how the record count reaches the host: count_path_from_env()
+#ifdef ADSB_AMD_STAMPS
+    unsigned long long* stamps_d = nullptr; // diagnostic builds: four clock values per launch, a ring of kStampSteps launches
+    unsigned            stamp_no = 0;
+#endif
     bool        logs_ok = true; // raw records go to per-wave logs (false once a log has overflowed: per-chunk regions from then on)
     std::string error;
 };
@@ -102,6 +112,35 @@ int fail(adsb_amd_ctx* c, int code, const char* msg)
 }
 
 constexpr uint32_t kDefaultCap = 32;
+#ifdef ADSB_AMD_STAMPS
+constexpr unsigned kStampSteps = 128, kStampGroups = 8192; // launches kept (a ring), workgroups per launch (scan_common.hip.h)
+#endif
+
+// How the record count of a scan reaches the host.
+//   kCountHost   (default): the ordering pass's last workgroup writes {count, overflow flag, launch stamp} as ONE 8-byte system-scope store
+//                into page-locked host memory and the host polls the stamp; nothing but the two kernels is on the scan's stream, and the record
+//                copy (copy stream) waits for the pass's event on the device.
+//   kCountCtl:   an 8-byte copy + event on a control stream behind the pass's event.  Cheap on the scan's stream, but the runtime's copy of
+//                eight bytes is a kernel, and beside a scan kernel that keeps every vector unit busy (the 2.4 MS/s mode) it got onto the
+//                chip 0.1-0.2 ms late: the host then submitted the next scan late and the GPU idled 75 us per step.
+//   kCountStream: the round-3 form, copy + event on the scan's own stream (11 us of that stream per step).
+// ADSB_AMD_COUNT_PATH=host|ctl|stream selects (A/B and fault-finding).
+enum : int { kCountHost = 0, kCountCtl = 1, kCountStream = 2 };
+int count_path_from_env()
+{
+    const char* e = std::getenv("ADSB_AMD_COUNT_PATH");
+    if (e && !std::strcmp(e, "ctl")) return kCountCtl;
+    if (e && !std::strcmp(e, "stream")) return kCountStream;
+    return kCountHost;
+}
+
+// The event between the ordering pass and the count's copy on the control stream orders device work only (the copy that follows it is
+// what the host sees): no system-scope release.  ADSB_AMD_ORDER_EVENT_FENCE=1 gives it one (A/B and fault-finding).
+unsigned order_event_flags()
+{
+    const char* e = std::getenv("ADSB_AMD_ORDER_EVENT_FENCE");
+    return (e && e[0] == '1') ? hipEventDefault : hipEventDisableSystemFence;
+}
 
 void free_slot(Slot& s)
 {
@@ -212,14 +251,34 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     // kernels do not get onto the chip while 4096 persistent workgroups are being placed.  Round 3, a third time, with what could
     // have kept it off a CU removed: the pass rewritten without LDS (a scan's sixteen waves hold all of a CU's) and held to 64 VGPRs
     // (the scan's waves leave that many per SIMD) -- 0.263 -> 0.313 and 0.280 -> 0.333 ms per step.)
-    HIP_TRY(c, hipEventRecord(s.ev_scan0, s.stream));
-    if (c->mode == ADSB_AMD_MODE_2400) HIP_TRY(c, launch_scan2400(s.args, s.total_d, s.stream));
-    else HIP_TRY(c, launch_scan1090(s.args, s.total_d, s.stream));
-    HIP_TRY(c, hipEventRecord(s.ev_scan1, s.stream));
+#ifdef ADSB_AMD_STAMPS
+    s.args.stamps = c->stamps_d ? c->stamps_d + (size_t)4 * kStampGroups * (c->stamp_no++ % kStampSteps) : nullptr;
+#endif
+    s.seq++;
+    s.events = c->timing_every != 0 && (c->submits++ % c->timing_every) == 0;
+    // the two timing events ride on the kernel's dispatch (scan1090.h); an empty input launches nothing and is not timed
+    s.events = s.events && s.args.total_chunks != 0;
+    if (c->mode == ADSB_AMD_MODE_2400) HIP_TRY(c, launch_scan2400(s.args, s.total_d, s.stream, s.events ? s.ev_scan0 : nullptr, s.events ? s.ev_scan1 : nullptr));
+    else HIP_TRY(c, launch_scan1090(s.args, s.total_d, s.stream, s.events ? s.ev_scan0 : nullptr, s.events ? s.ev_scan1 : nullptr));
     HIP_TRY(c, launch_order1090(s.args, (s.produced & ADSB_AMD_OUT_RECORDS) ? s.dense : nullptr, (s.produced & ADSB_AMD_OUT_DECODED) ? s.decoded : nullptr,
-                                (s.produced & ADSB_AMD_OUT_PACKED) ? s.packed : nullptr, next_sums, (uint32_t)(s.sums_words / kSumStride), s.total_d, s.stream));
-    HIP_TRY(c, hipMemcpyAsync(s.total_h, s.total_d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(c, hipEventRecord(s.ev_done, s.stream));
+                                (s.produced & ADSB_AMD_OUT_PACKED) ? s.packed : nullptr, next_sums, (uint32_t)(s.sums_words / kSumStride), s.total_d, s.stream, s.args.total_chunks ? s.ev_order : nullptr,
+                                c->count_path == kCountHost ? s.total_h_dev : nullptr, s.seq));
+    if (!s.args.total_chunks) HIP_TRY(c, hipEventRecord(s.ev_order, s.stream)); // (otherwise the ordering pass's dispatch carries it)
+    if (c->count_path == kCountHost)
+    {
+        if (!s.args.total_chunks) __atomic_store_n(s.total_h, (unsigned long long)(s.seq & 0x7FFFFFFFu) << 33, __ATOMIC_RELEASE); // nothing was launched: no records
+    }
+    else if (c->count_path == kCountCtl)
+    {
+        HIP_TRY(c, hipStreamWaitEvent(c->ctl_stream, s.ev_order, 0));
+        HIP_TRY(c, hipMemcpyAsync(s.total_h, s.total_d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->ctl_stream));
+        HIP_TRY(c, hipEventRecord(s.ev_done, c->ctl_stream));
+    }
+    else
+    {
+        HIP_TRY(c, hipMemcpyAsync(s.total_h, s.total_d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(c, hipEventRecord(s.ev_done, s.stream));
+    }
     return ADSB_AMD_OK;
 }
 } // namespace
@@ -276,6 +335,8 @@ extern "C" int adsb_amd_create_mode(adsb_amd_ctx_t** out, int device, int mode)
     }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->ctl_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    c->count_path = count_path_from_env();
 
     uint32_t tab[112];
     build_crc_table(tab);
@@ -287,16 +348,49 @@ extern "C" int adsb_amd_create_mode(adsb_amd_ctx_t** out, int device, int mode)
         if ((e = hipMemset(s.total_d, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(total)", e);
         if ((e = hipMalloc(&s.work_d, kWorkCounters * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(work)", e);
         if ((e = hipMemset(s.work_d, 0, kWorkCounters * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(work)", e);
-        if ((e = hipHostMalloc(&s.total_h, 2 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(total)", e);
+        if ((e = hipHostMalloc(&s.total_h, sizeof(unsigned long long), hipHostMallocMapped)) != hipSuccess) return bail("hipHostMalloc(total)", e);
+        *s.total_h = 0;
+        if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&s.total_h_dev), s.total_h, 0)) != hipSuccess) return bail("hipHostGetDevicePointer(total)", e);
         // The two events around the scan kernel are read for their time stamps only, after ev_done has been waited for: no system-scope
         // release when they are recorded (an event costs ~5 us of stream time with it, ~3 without; a fourth event per step is gone).
         if ((e = hipEventCreateWithFlags(&s.ev_scan0, hipEventDisableSystemFence)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&s.ev_scan1, hipEventDisableSystemFence)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&s.ev_order, order_event_flags())) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreate(&s.ev_done)) != hipSuccess) return bail("hipEventCreate", e);
     }
+#ifdef ADSB_AMD_STAMPS
+    if ((e = hipMalloc(&c->stamps_d, (size_t)kStampSteps * 4 * kStampGroups * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(stamps)", e);
+    if ((e = hipMemset(c->stamps_d, 0, (size_t)kStampSteps * 4 * kStampGroups * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset(stamps)", e);
+#endif
     *out = c;
     return ADSB_AMD_OK;
 }
+
+#ifdef ADSB_AMD_STAMPS
+// diagnostic builds: per launch of the ring {scan first in, scan last out, ordering pass first in, last out} (0 where nothing was noted), and
+// how many launches there have been
+extern "C" int adsb_amd_debug_stamps(adsb_amd_ctx_t* c, unsigned long long* out /* kStampSteps x 4 */, unsigned* launches)
+{
+    if (!c || !out || !launches) return ADSB_AMD_EINVAL;
+    HIP_TRY(c, hipDeviceSynchronize());
+    std::vector<unsigned long long> all((size_t)kStampSteps * 4 * kStampGroups);
+    HIP_TRY(c, hipMemcpy(all.data(), c->stamps_d, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < (size_t)kStampSteps * 4; k++)
+    {
+        unsigned long long lo = ~0ull, hi = 0;
+        for (size_t g = 0; g < kStampGroups; g++)
+        {
+            const unsigned long long v = all[k * kStampGroups + g];
+            if (v == 0) continue;
+            lo = std::min(lo, v);
+            hi = std::max(hi, v);
+        }
+        out[k] = hi == 0 ? 0 : ((k & 1) ? hi : lo);
+    }
+    *launches = c->stamp_no;
+    return ADSB_AMD_OK;
+}
+#endif
 
 extern "C" void adsb_amd_destroy(adsb_amd_ctx_t* c)
 {
@@ -304,6 +398,7 @@ extern "C" void adsb_amd_destroy(adsb_amd_ctx_t* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->ctl_stream) (void)hipStreamSynchronize(c->ctl_stream);
     for (Slot& s : c->slot)
     {
         free_slot(s);
@@ -315,6 +410,7 @@ extern "C" void adsb_amd_destroy(adsb_amd_ctx_t* c)
         if (s.host_packed) (void)hipHostFree(s.host_packed);
         if (s.ev_scan0) (void)hipEventDestroy(s.ev_scan0);
         if (s.ev_scan1) (void)hipEventDestroy(s.ev_scan1);
+        if (s.ev_order) (void)hipEventDestroy(s.ev_order);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     }
     if (c->crc_tab) (void)hipFree(c->crc_tab);
@@ -322,6 +418,7 @@ extern "C" void adsb_amd_destroy(adsb_amd_ctx_t* c)
     if (c->staging) (void)hipFree(c->staging);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->ctl_stream) (void)hipStreamDestroy(c->ctl_stream);
     delete c;
 }
 
@@ -355,12 +452,66 @@ namespace
 // with regions eight times larger, up to the hard bound of two records per preamble position -- as long as the record arrays
 // (regions + dense + decoded) still fit in free device memory; beyond that the call fails with ADSB_AMD_ENOMEM instead of leaning on
 // hipMalloc to refuse.  The region size that worked is remembered for BOTH slots (the other one starts its next scan with it).
+// The slot's record count and overflow flag -> s.nrecords, s.overflow (see count_path_from_env).
+int wait_count(adsb_amd_ctx* c, Slot& s)
+{
+    if (c->count_path != kCountHost)
+    {
+        HIP_TRY(c, hipEventSynchronize(s.ev_done));
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(s.total_h);
+        s.nrecords        = w[0];
+        s.overflow        = w[1] != 0;
+        return ADSB_AMD_OK;
+    }
+    // Poll the stamp.  The word is written once per launch, by one store; the pass's event is asked now and then so that a launch that
+    // failed (the event completes in error, or completes without the word ever arriving) ends the wait instead of hanging it.
+    const unsigned long long want = s.seq & 0x7FFFFFFFu;
+    for (unsigned spins = 0;; spins++)
+    {
+        const unsigned long long w = __atomic_load_n(s.total_h, __ATOMIC_ACQUIRE);
+        if ((w >> 33) == want)
+        {
+            s.nrecords = (uint32_t)w;
+            s.overflow = ((w >> 32) & 1u) != 0;
+            return ADSB_AMD_OK;
+        }
+        if ((spins & 0x3FFu) == 0x3FFu)
+        {
+            const hipError_t q = hipEventQuery(s.ev_order);
+            if (q == hipSuccess)
+            { // the pass is done: its store has left the device; give it a moment to land, then it is an error
+                for (int k = 0; k < 1000000; k++)
+                {
+                    const unsigned long long w2 = __atomic_load_n(s.total_h, __ATOMIC_ACQUIRE);
+                    if ((w2 >> 33) == want)
+                    {
+                        s.nrecords = (uint32_t)w2;
+                        s.overflow = ((w2 >> 32) & 1u) != 0;
+                        return ADSB_AMD_OK;
+                    }
+                    __builtin_ia32_pause();
+                }
+                return fail(c, ADSB_AMD_EHIP, "the ordering pass finished without delivering its record count");
+            }
+            if (q != hipErrorNotReady)
+            {
+                c->error = std::string("scan failed: ") + hipGetErrorString(q);
+                return ADSB_AMD_EHIP;
+            }
+        }
+        __builtin_ia32_pause();
+    }
+}
+
 int wait_scan(adsb_amd_ctx* c, Slot& s)
 {
     for (;;)
     {
-        HIP_TRY(c, hipEventSynchronize(s.ev_done));
-        if (s.total_h[1] == 0) break;
+        {
+            const int rc = wait_count(c, s);
+            if (rc) return rc;
+        }
+        if (!s.overflow) break;
         if (s.args.log_cap)
         { // a wave's log was full (input far denser than the regions were sized for): once more with a region per chunk, same memory
             c->logs_ok = false;
@@ -401,11 +552,11 @@ int fetch_slot(adsb_amd_ctx* c, Slot& s, unsigned what)
         const int rc = wait_scan(c, s);
         if (rc) return rc;
     }
-    s.nrecords = s.total_h[0];
-    int rc     = ensure_host(c, s, s.nrecords);
+    int rc = ensure_host(c, s, s.nrecords);
     if (rc) return rc;
     if (s.nrecords)
     {
+        if (c->count_path == kCountHost) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, s.ev_order, 0)); // the count comes from the pass's last workgroup, others may still be moving records
         if (what & ADSB_AMD_OUT_RECORDS)
             HIP_TRY(c, hipMemcpyAsync(s.host, s.dense, s.nrecords * sizeof(adsb_amd_record_t), hipMemcpyDeviceToHost, c->copy_stream));
         if (what & ADSB_AMD_OUT_DECODED)
@@ -415,9 +566,12 @@ int fetch_slot(adsb_amd_ctx* c, Slot& s, unsigned what)
         HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     }
     s.dec_valid = (what & ADSB_AMD_OUT_DECODED) != 0;
-    s.timed     = true;
-    (void)hipEventElapsedTime(&s.scan_ms, s.ev_scan0, s.ev_scan1);
-    (void)hipEventElapsedTime(&s.total_ms, s.ev_scan0, s.ev_done); // the scan is the first thing a submit enqueues
+    s.timed     = s.events;
+    if (s.events)
+    {
+        (void)hipEventElapsedTime(&s.scan_ms, s.ev_scan0, s.ev_scan1);
+        (void)hipEventElapsedTime(&s.total_ms, s.ev_scan0, c->count_path == kCountHost ? s.ev_order : s.ev_done); // the scan is the first thing a submit enqueues
+    }
     return ADSB_AMD_OK;
 }
 } // namespace
@@ -427,6 +581,14 @@ extern "C" int adsb_amd_set_outputs(adsb_amd_ctx_t* c, unsigned mask)
     if (!c) return ADSB_AMD_EINVAL;
     if (mask == 0 || (mask & ~(ADSB_AMD_OUT_RECORDS | ADSB_AMD_OUT_DECODED | ADSB_AMD_OUT_PACKED))) return fail(c, ADSB_AMD_EINVAL, "outputs: a non-empty combination of ADSB_AMD_OUT_*");
     c->outputs = mask;
+    return ADSB_AMD_OK;
+}
+
+extern "C" int adsb_amd_set_timing(adsb_amd_ctx_t* c, unsigned every)
+{
+    if (!c) return ADSB_AMD_EINVAL;
+    c->timing_every = every;
+    c->submits      = 0;
     return ADSB_AMD_OK;
 }
 
@@ -506,7 +668,6 @@ int fetch_device_impl(adsb_amd_ctx_t* c, int slot, void* dst_device, size_t cap,
             const int rc = wait_scan(c, s); // repeats the scan with larger regions when a chunk overflowed its region
             if (rc) return rc;
         }
-        s.nrecords = s.total_h[0];
         if (n) *n = s.nrecords;
         if (!(s.produced & (packed ? ADSB_AMD_OUT_PACKED : ADSB_AMD_OUT_RECORDS)))
             return fail(c, ADSB_AMD_ESTATE, "this slot's scan did not produce the array asked for (adsb_amd_set_outputs)");
@@ -514,15 +675,19 @@ int fetch_device_impl(adsb_amd_ctx_t* c, int slot, void* dst_device, size_t cap,
         if (s.nrecords)
         {
             hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->copy_stream;
+            if (c->count_path == kCountHost) HIP_TRY(c, hipStreamWaitEvent(st, s.ev_order, 0));
             // hipMemcpyDefault: the destination may be device memory or page-locked / registered host memory (shard.NodeGather)
             static_assert(sizeof(adsb_amd_record_t) == sizeof(adsb_amd_packed_t), "one size for both forms");
             HIP_TRY(c, hipMemcpyAsync(dst_device, packed ? static_cast<const void*>(s.packed) : static_cast<const void*>(s.dense),
                                       s.nrecords * sizeof(adsb_amd_record_t), hipMemcpyDefault, st));
             if (!hip_stream) HIP_TRY(c, hipStreamSynchronize(st));
         }
-        s.timed = true;
-        (void)hipEventElapsedTime(&s.scan_ms, s.ev_scan0, s.ev_scan1);
-        (void)hipEventElapsedTime(&s.total_ms, s.ev_scan0, s.ev_done); // the scan is the first thing a submit enqueues
+        s.timed = s.events;
+        if (s.events)
+        {
+            (void)hipEventElapsedTime(&s.scan_ms, s.ev_scan0, s.ev_scan1);
+            (void)hipEventElapsedTime(&s.total_ms, s.ev_scan0, c->count_path == kCountHost ? s.ev_order : s.ev_done); // the scan is the first thing a submit enqueues
+        }
         return ADSB_AMD_OK;
     };
     const int rc = body();
@@ -536,7 +701,7 @@ extern "C" int adsb_amd_scan_1090_timing(adsb_amd_ctx_t* c, int slot, float* sca
     if (!c) return ADSB_AMD_EINVAL;
     if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
     Slot& s = c->slot[slot];
-    if (!s.timed) return fail(c, ADSB_AMD_ESTATE, "no completed scan on this slot");
+    if (!s.timed) return fail(c, ADSB_AMD_ESTATE, "no completed, timed scan on this slot (adsb_amd_set_timing)");
     if (scan_kernel_ms) *scan_kernel_ms = s.scan_ms;
     if (total_ms) *total_ms = s.total_ms;
     return ADSB_AMD_OK;

@@ -52,11 +52,17 @@ struct ScanArgs
     uint32_t*          work_counters; // kSubRanges per XCD, counter c at [32 * c] (own cache line each), zero when the scan starts; the ordering pass zeroes them again
     uint32_t           nxcd;          // XCDs of the device (hipDeviceAttributeNumberOfXccs; 8 on MI355X), <= kMaxXcd
     uint32_t           ncu;           // compute units of the device (256 on MI355X)
+#ifdef ADSB_AMD_STAMPS
+    unsigned long long* stamps;       // diagnostic builds (tools/stamps.py): {scan first wave in, scan last wave out, ordering pass in, out} of this launch, 100 MHz clock
+#endif
     uint32_t*          block_sums;    // one padded entry (kSumStride words) per kOrderChunks chunks, zero when the scan starts: [0] += records of a
                                       // finished chunk (clamped to cap), [1] |= 1 when a chunk found more than cap
 };
 constexpr uint32_t kOrderChunks = 256; // chunks per entry of block_sums = per workgroup of the ordering pass
-constexpr uint32_t kSumStride   = 32;  // words between entries: an entry per 128-byte line (one atomic per chunk lands on it)
+#ifndef ADSB_AMD_SUM_STRIDE
+#define ADSB_AMD_SUM_STRIDE 32
+#endif
+constexpr uint32_t kSumStride   = ADSB_AMD_SUM_STRIDE;  // words between entries: an entry per 128-byte line (one atomic per chunk lands on it)
 
 constexpr uint32_t kSubRanges   = 4;  // work counters per XCD
 constexpr uint32_t kMaxXcd      = 16;
@@ -81,14 +87,20 @@ inline uint32_t scan_grid(const ScanArgs& a)
 }
 
 // Demodulation kernel (fills the raw record regions / logs and the chunk directory; zeroes `total_and_overflow`).
-hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream);
+// `start` / `stop` (both or neither): events that take the kernel's own start and end times -- they ride on the dispatch
+// (hipExtLaunchKernelGGL), where two hipEventRecord calls around the launch are packets of their own on the stream, 3-5 us each.
+hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // Ordering pass: the sorted gather into `dense` (+ field decode).  `total_and_overflow` is a device uint32_t[2]: {number of
 // records in dense, overflow flag}.  a.block_sums holds what the scan accumulated; `next_block_sums` (`next_entries` padded entries, the
 // slot's whole second array) is zeroed for the next scan of this slot, and so are the work counters.  (Letting the pass write the two words into page-locked host memory
 // itself, instead of the 8-byte copy that follows it in the stream, was measured 40 us per step slower.)
 // dense / decoded / packed: the arrays to produce (any may be NULL)
+// `done` (may be NULL): event that takes the pass's end (riding on its dispatch like the scan's two)
 hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, adsb_amd_decoded_t* decoded, adsb_amd_packed_t* packed, uint32_t* next_block_sums,
-                            uint32_t next_entries, uint32_t* total_and_overflow, hipStream_t stream);
+                            uint32_t next_entries, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t done = nullptr,
+                            unsigned long long* host_word = nullptr, uint32_t stamp = 0);
+// host_word (may be NULL): device address of 8 bytes of page-locked host memory; the pass's last workgroup stores
+// count | (stamp << 1 | overflow flag) << 32 there, one system-scope store (stamp: 31 bits)
 // the field decoder of the ordering pass over an arbitrary device record array (parity helper)
 hipError_t launch_decode1090(const adsb_amd_record_t* rec, adsb_amd_decoded_t* out, size_t n, hipStream_t stream);
 
@@ -100,7 +112,7 @@ hipError_t launch_phase978(const uint8_t* iq, uint16_t* phi, size_t nsamples, co
 
 // ---- the 2.4 MS/s mode (scan2400.hip; definition: oracle/oracle2400.c).  Same ScanArgs, same raw records, same ordering pass.
 uint32_t   chunks_per_buffer_2400(uint32_t buf_samples);
-hipError_t launch_scan2400(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream);
+hipError_t launch_scan2400(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 
 // host-side table builders (exact integer / polynomial arithmetic, no reference text)
 void build_crc_table(uint32_t* tab /* 112 */);

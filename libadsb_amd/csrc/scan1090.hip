@@ -29,6 +29,7 @@
 // HBM traffic: the IQ bytes once (+6 % halo, normally an L2 hit: neighbouring chunks are scheduled on
 // the same XCD) and 32 B per record.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <math.h>
 #include <stdint.h>
@@ -461,6 +462,9 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
     uint16_t* const                                  queue = reinterpret_cast<uint16_t*>(&tile32[kTileDwords]);
 
     const int        lane = threadIdx.x;
+#ifdef ADSB_AMD_STAMPS
+    stamp(a.stamps, 0);
+#endif
     const LaneTables lt   = load_lane_tables(a.crc_tab, lane);
     const FastConsts fc   = fast_consts(lane);
     const uint32_t   tile_addr = lds_address(tile32), queue_addr = lds_address(queue);
@@ -700,6 +704,61 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         }
     }
     flush_records();
+#ifdef ADSB_AMD_STAMPS
+    stamp(a.stamps, 1);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// The field decoder of decode1090.h (decode_record) for the ordering pass: the same function of the message, written for a vector unit
+// that runs every branch some lane of the wave takes (a wave of 64 records has every kind of message in it, so the byte-wise version
+// cost the pass all its branches one after the other: 4.4 of its 13 us).  Straight-line bit-field arithmetic on the message as big-endian
+// words B0..B2 (B0 = bytes 0-3, first byte on top), one select per result at the end; the identification's eight characters come out of
+// a 64-byte table in LDS (eight byte reads instead of eight chains of comparisons).  Checked against the host build record by
+// record (tests: the 4.2 M velocity pairs, every identification character, random records of every DF).
+// ---------------------------------------------------------------------------------------------
+struct FieldsDev
+{
+    uint32_t head;     // kind | metype << 8 | mesub << 16 | odd << 24 (adsb_amd_decoded_t's first four bytes)
+    uint32_t altitude; // int32
+    uint32_t a, b;
+};
+__device__ __forceinline__ void ais_table_init(uint8_t* tab /* 64, LDS */, uint32_t t)
+{
+    if (t < 64u) tab[t] = (uint8_t)ais_char(t);
+}
+__device__ __forceinline__ FieldsDev decode_fields_dev(uint32_t B0, uint32_t B1, uint32_t B2, uint32_t df, const uint8_t* ais /* LDS */)
+{
+    const uint32_t metype = B1 >> 27, mesub = (B1 >> 24) & 7u;
+    // DF0/4/20: the 13-bit AC field, bytes 2-3 (:440-466)
+    const uint32_t ac13 = B0 & 0x1FFFu;
+    const int      n13  = (int)(((ac13 & 0x1F80u) >> 2) | ((ac13 & 0x20u) >> 1) | (ac13 & 0xFu));
+    const int      alt13 = ((ac13 & 0x40u) || !(ac13 & 0x10u)) ? 0 : n13 * 25 - 1000;
+    // airborne position (:622-630, 470-486): AC12 = bytes 5 and 6's high nibble, F flag, 17-bit raw latitude and longitude
+    const uint32_t ac12  = (B1 >> 12) & 0xFFFu;
+    const int      alt12 = (ac12 & 0x10u) ? (int)(((ac12 >> 5) << 4) | (ac12 & 0xFu)) * 25 - 1000 : 0;
+    const uint32_t lat   = ((B1 & 0x3FFu) << 7) | (B2 >> 25), lon = (B2 >> 8) & 0x1FFFFu, odd = (B1 >> 10) & 1u;
+    // airborne velocity (:631-660)
+    const int ew = (int)((B1 >> 8) & 0x3FFu), ns = (int)(((B1 & 0x7Fu) << 3) | (B2 >> 29));
+    const int n  = ns * ns + ew * ew;
+    int       v  = (int)__builtin_sqrtf((float)n); // within one of the integer square root (n < 2^21 is exact in a float)
+    v -= (v * v > n) ? 1 : 0;
+    v += ((v + 1) * (v + 1) <= n) ? 1 : 0;
+    const int h = v ? heading_of((B1 & (1u << 18)) ? -ew : ew, (B1 & 0x80u) ? -ns : ns) : 0;
+    // identification (:608-619): eight 6-bit characters in bytes 5-10
+    const uint32_t c03 = B1 & 0xFFFFFFu, c47 = B2 >> 8;
+    const uint32_t ia = (uint32_t)ais[c03 >> 18] | ((uint32_t)ais[(c03 >> 12) & 63u] << 8) | ((uint32_t)ais[(c03 >> 6) & 63u] << 16) | ((uint32_t)ais[c03 & 63u] << 24);
+    const uint32_t ib = (uint32_t)ais[c47 >> 18] | ((uint32_t)ais[(c47 >> 12) & 63u] << 8) | ((uint32_t)ais[(c47 >> 6) & 63u] << 16) | ((uint32_t)ais[c47 & 63u] << 24);
+
+    const bool is_alt = df == 0u || df == 4u || df == 20u, es = df == 17u;
+    const bool is_id = es && metype - 1u < 4u, is_pos = es && metype - 9u < 10u, is_vel = es && metype == 19u && mesub - 1u < 2u;
+    FieldsDev  f;
+    const uint32_t kind = is_alt ? (uint32_t)ADSB_AMD_K_ALTITUDE : is_id ? (uint32_t)ADSB_AMD_K_IDENT : is_pos ? (uint32_t)ADSB_AMD_K_POSITION : is_vel ? (uint32_t)ADSB_AMD_K_VELOCITY : 0u;
+    f.head     = kind | (metype << 8) | (mesub << 16) | ((is_pos ? odd : 0u) << 24);
+    f.altitude = (uint32_t)(is_alt ? alt13 : is_pos ? alt12 : 0);
+    f.a        = is_id ? ia : is_pos ? lat : is_vel ? (uint32_t)v : 0u;
+    f.b        = is_id ? ib : is_pos ? lon : is_vel ? (uint32_t)h : 0u;
+    return f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -714,9 +773,6 @@ constexpr uint32_t kOrderBlock   = 256;  // chunks per workgroup of the ordering
 constexpr uint32_t kOrderThreads = ADSB_AMD_ORDER_THREADS; // its threads = records it moves per trip (a block of a quiet band holds ~550); two workgroups per CU
 static_assert(kOrderThreads % 64 == 0 && kOrderThreads >= kOrderBlock && kOrderThreads <= 1024, "whole waves, at least the chunk threads");
 
-// reverse the bit order inside each byte: message bit n (n = 8k + b, b = 0 first/MSB) -> bit 7-b of byte k
-__device__ __forceinline__ uint32_t msg_bytes(uint32_t bits) { return __builtin_bswap32(__builtin_bitreverse32(bits)); }
-
 // Round 4.  Until then a thread walked its chunk's records one after the other -- load the record, count the chunk's smaller keys, decode,
 // store, next -- and a wave took as long as its longest chunk: seven dependent trips of a memory round trip each where the average chunk
 // has two records, 28-31 us for 18 MB.  Now the chunk threads only publish where their records start (LDS), every record gets a lane of
@@ -728,14 +784,23 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
                                                             adsb_amd_record_t* __restrict__ dense, adsb_amd_decoded_t* __restrict__ decoded,
                                                             adsb_amd_packed_t* __restrict__ packed, uint32_t* __restrict__ total_overflow,
                                                             uint32_t* __restrict__ next_block_sums,
-                                                            uint32_t next_entries, uint32_t* __restrict__ work_counters)
+                                                            uint32_t next_entries, uint32_t* __restrict__ work_counters, unsigned long long* stamps,
+                                                            unsigned long long* host_word, uint32_t stamp_no)
 {
     constexpr uint32_t kWaves = kOrderThreads / 64;
+    stamp(stamps, 2);
+    struct StampOut
+    {
+        unsigned long long* st;
+        __device__ ~StampOut() { stamp(st, 3); }
+    } stamp_on_exit{stamps};
     __shared__ uint32_t before_w[kWaves], count_w[kOrderBlock / 64];
     __shared__ uint32_t cstart[kOrderBlock + 1]; // first record of each chunk among the block's records, and their total
     __shared__ uint32_t csrc[kOrderBlock];       // log mode: index of the chunk's first raw record
     __shared__ uint8_t  owner[kOrderThreads];    // chunk (within the block) of record `trip base + t`
+    __shared__ uint8_t  ais[64];                 // the identification message's character set (decode_fields_dev)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    ais_table_init(ais, tid); // (the barrier behind the prefix sums comes before its first reader)
     // housekeeping for the next scan of this slot: its block sums (the other of two arrays, all of it: the next input may be larger
     // than this one) and the work counters start from zero
     for (uint32_t k = blockIdx.x * kOrderThreads + tid; k < 2u * next_entries; k += nblocks * kOrderThreads)
@@ -745,6 +810,10 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
     // records in earlier blocks, and this block's chunk counts
     uint32_t before = 0;
     for (uint32_t b = tid; b < blockIdx.x; b += kOrderThreads) before += block_sums[b * kSumStride];
+    // the last workgroup also tells the host (host_word): it reads every block's overflow flag for that
+    bool any_over = false;
+    if (host_word && blockIdx.x == nblocks - 1)
+        for (uint32_t b = tid; b < nblocks; b += kOrderThreads) any_over = any_over || block_sums[b * kSumStride + 1] != 0;
     const uint32_t c  = blockIdx.x * kOrderBlock + tid;
     const uint2    de = (tid < kOrderBlock && c < nchunks) ? *reinterpret_cast<const uint2*>(chunk_dir + 2ull * c) : make_uint2(0u, 0u); // {first raw record (log mode), records kept}
     const uint32_t n  = de.y;
@@ -776,6 +845,16 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
     }
     if (tid == 0) cstart[kOrderBlock] = tot;
     if (blockIdx.x == nblocks - 1 && tid == 0) total_overflow[0] = base + tot;
+    if (host_word && blockIdx.x == nblocks - 1)
+    { // (all waves of the workgroup come here: the sync is not divergent)
+        const int over = __syncthreads_or(any_over ? 1 : 0);
+        if (tid == 0)
+            __hip_atomic_store(host_word, (unsigned long long)(base + tot) | ((unsigned long long)(((stamp_no & 0x7FFFFFFFu) << 1) | (over ? 1u : 0u)) << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+#if defined(ADSB_AMD_ORDER_PARTS) && ADSB_AMD_ORDER_PARTS == 1 // profiling builds (wrong results): 1 = the prefix only, 2 = + fetch and store (no ranks, no decode), 3 = + ranks
+    return;
+#endif
 
     for (uint32_t trip = 0; trip < tot; trip += kOrderThreads)
     {
@@ -793,6 +872,9 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
         // rank among the chunk's records by (offset, pass): their keys four at a time (a chunk seldom has more)
         const uint32_t key = (lo.x << 1) | ((lo.y >> 16) & 1u);
         uint32_t       rank = 0;
+#if defined(ADSB_AMD_ORDER_PARTS) && ADSB_AMD_ORDER_PARTS == 2
+        rank = i;
+#else
         for (uint32_t k0 = 0; k0 < nn; k0 += 4)
         {
             uint2 q[4];
@@ -801,6 +883,7 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) rank += (((q[k].x << 1) | ((q[k].y >> 16) & 1u)) < key) ? 1u : 0u;
         }
+#endif
         const uint32_t buffer = ch / chunks_per_buf;
         const size_t   out    = (size_t)base + first + rank;
         // raw -> adsb_amd_record_t: apply the 1-bit repair, order the bytes, pull the address out
@@ -814,38 +897,34 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
             else if (errorbit < 96) hi.z ^= m;
             else hi.w ^= m;
         }
-        const uint32_t m0 = msg_bytes(hi.x), m1 = msg_bytes(hi.y), m2 = msg_bytes(hi.z), m3 = msg_bytes(hi.w); // bytes 0-3, 4-7, 8-11, 12-13
-        const uint32_t addr = (flags & ADSB_AMD_F_NEEDS_ICAO) ? lo.z : (((m0 >> 8) & 0xFFu) << 16 | ((m0 >> 16) & 0xFFu) << 8 | (m0 >> 24));
-        uint4 o0, o1;
+        // the message as big-endian words (first bit on top) and as bytes in memory order
+        const uint32_t B0 = __builtin_bitreverse32(hi.x), B1 = __builtin_bitreverse32(hi.y), B2 = __builtin_bitreverse32(hi.z), B3 = __builtin_bitreverse32(hi.w);
+        const uint32_t m0 = __builtin_bswap32(B0), m1 = __builtin_bswap32(B1), m2 = __builtin_bswap32(B2), m3 = __builtin_bswap32(B3); // bytes 0-3, 4-7, 8-11, 12-13
+        const uint32_t addr = (flags & ADSB_AMD_F_NEEDS_ICAO) ? lo.z : (B0 & 0xFFFFFFu);
+        uint4 o0;
         o0.x = buffer;
         o0.y = lo.x;
         o0.z = addr;
         o0.w = (lo.w & 0xFFFFu) | (nbits << 16) | (((uint32_t)errorbit & 0xFFu) << 24);
-        o1.x = df | (flags << 8) | (m0 << 16);
-        o1.y = (m0 >> 16) | (m1 << 16);
-        o1.z = (m1 >> 16) | (m2 << 16);
-        o1.w = (m2 >> 16) | (m3 << 16);
         if (dense)
         {
             uint4* o = reinterpret_cast<uint4*>(dense + out);
             o[0]     = o0;
-            o[1]     = o1;
+            o[1]     = make_uint4(df | (flags << 8) | (m0 << 16), (m0 >> 16) | (m1 << 16), (m1 >> 16) | (m2 << 16), (m2 >> 16) | (m3 << 16));
         }
-        // the stateless half of DecodeModesMessage (decode1090.h), so that the host's sequential pass decodes nothing
-        uint8_t g[16];
-        g[0] = (uint8_t)m0; g[1] = (uint8_t)(m0 >> 8); g[2] = (uint8_t)(m0 >> 16); g[3] = (uint8_t)(m0 >> 24);
-        g[4] = (uint8_t)m1; g[5] = (uint8_t)(m1 >> 8); g[6] = (uint8_t)(m1 >> 16); g[7] = (uint8_t)(m1 >> 24);
-        g[8] = (uint8_t)m2; g[9] = (uint8_t)(m2 >> 8); g[10] = (uint8_t)(m2 >> 16); g[11] = (uint8_t)(m2 >> 24);
-        g[12] = (uint8_t)m3; g[13] = (uint8_t)(m3 >> 8);
-        const adsb_amd_decoded_t d = decode_record(g, (int)df);
-        if (decoded)
-            *reinterpret_cast<uint4*>(decoded + out) =
-                make_uint4((uint32_t)d.kind | ((uint32_t)d.metype << 8) | ((uint32_t)d.mesub << 16) | ((uint32_t)d.odd << 24), (uint32_t)d.altitude, d.a, d.b);
+        // the stateless half of DecodeModesMessage, so that the host's sequential pass decodes nothing
+#if defined(ADSB_AMD_ORDER_PARTS) && ADSB_AMD_ORDER_PARTS <= 3
+        FieldsDev d{};
+        d.a = B1 ^ key;
+#else
+        const FieldsDev d = decode_fields_dev(B0, B1, B2, df, ais);
+#endif
+        if (decoded) *reinterpret_cast<uint4*>(decoded + out) = make_uint4(d.head, d.altitude, d.a, d.b);
         if (packed)
         { // the record's first sixteen bytes, then df, flags, kind, odd and the decoded values (adsb_amd_packed_t)
             uint4* o = reinterpret_cast<uint4*>(packed + out);
             o[0]     = o0;
-            o[1]     = make_uint4(df | (flags << 8) | ((uint32_t)d.kind << 16) | ((uint32_t)d.odd << 24), (uint32_t)d.altitude, d.a, d.b);
+            o[1]     = make_uint4(df | (flags << 8) | ((d.head & 0xFFu) << 16) | (d.head & 0xFF000000u), d.altitude, d.a, d.b);
         }
     }
 }
@@ -853,11 +932,16 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
 // parity helper: the same decoder over an arbitrary record array
 __global__ __launch_bounds__(256) void decode1090_kernel(const adsb_amd_record_t* __restrict__ rec, adsb_amd_decoded_t* __restrict__ out, size_t n)
 {
+    __shared__ uint8_t ais[64];
+    ais_table_init(ais, threadIdx.x);
+    __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint8_t g[14];
-    for (int k = 0; k < 14; k++) g[k] = rec[i].msg[k];
-    out[i] = decode_record(g, rec[i].df);
+    uint32_t B[3];
+    for (int k = 0; k < 3; k++)
+        B[k] = ((uint32_t)rec[i].msg[4 * k] << 24) | ((uint32_t)rec[i].msg[4 * k + 1] << 16) | ((uint32_t)rec[i].msg[4 * k + 2] << 8) | (uint32_t)rec[i].msg[4 * k + 3];
+    const FieldsDev d = decode_fields_dev(B[0], B[1], B[2], rec[i].df, ais); // what the ordering pass runs
+    *reinterpret_cast<uint4*>(out + i) = make_uint4(d.head, d.altitude, d.a, d.b);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -889,12 +973,13 @@ __global__ __launch_bounds__(256) void phase978_kernel(const uint8_t* __restrict
 
 } // namespace
 
-hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream)
+hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start, hipEvent_t stop)
 {
     if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
     // persistent single-wave workgroups: enough to fill every CU at the LDS-limited occupancy (16 per CU)
     const uint32_t grid = scan_grid(a);
-    hipLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
+    if (start && stop) hipExtLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, start, stop, 0, a, total_and_overflow);
+    else hipLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
     return hipGetLastError();
 }
 
@@ -906,13 +991,24 @@ hipError_t launch_decode1090(const adsb_amd_record_t* rec, adsb_amd_decoded_t* o
 }
 
 hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, adsb_amd_decoded_t* decoded, adsb_amd_packed_t* packed, uint32_t* next_block_sums,
-                            uint32_t next_entries, uint32_t* total_and_overflow, hipStream_t stream)
+                            uint32_t next_entries, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t done, unsigned long long* host_word, uint32_t stamp)
 {
     if (a.total_chunks == 0) return hipSuccess;
     static_assert(kOrderBlock == kOrderChunks, "one block-sum entry per workgroup of the ordering pass");
     const uint32_t nblocks = (a.total_chunks + kOrderBlock - 1u) / kOrderBlock;
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderThreads), 0, stream, a.chunk_records, a.chunk_dir, a.block_sums,
-                       a.total_chunks, nblocks, a.cap, a.log_cap, a.chunks_per_buf, dense, decoded, packed, total_and_overflow, next_block_sums, next_entries, a.work_counters);
+#ifdef ADSB_AMD_STAMPS
+    unsigned long long* const stamps = a.stamps;
+#else
+    unsigned long long* const stamps = nullptr;
+#endif
+    if (done)
+        hipExtLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderThreads), 0, stream, nullptr, done, 0, a.chunk_records, a.chunk_dir, a.block_sums,
+                       a.total_chunks, nblocks, a.cap, a.log_cap, a.chunks_per_buf, dense, decoded, packed, total_and_overflow, next_block_sums, next_entries, a.work_counters,
+                       stamps, host_word, stamp);
+    else
+        hipLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderThreads), 0, stream, a.chunk_records, a.chunk_dir, a.block_sums,
+                       a.total_chunks, nblocks, a.cap, a.log_cap, a.chunks_per_buf, dense, decoded, packed, total_and_overflow, next_block_sums, next_entries, a.work_counters,
+                       stamps, host_word, stamp);
     return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@
 //     margin --, ballots give the message, parity is the DPP XOR reduction of per-lane table entries, the one-bit repair a
 //     ballot over per-lane syndromes (shared with the 2 MS/s kernel).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <stdint.h>
 
@@ -223,6 +224,9 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     uint16_t* const                                  img16 = reinterpret_cast<uint16_t*>(img);
 
     const int        lane = threadIdx.x;
+#ifdef ADSB_AMD_STAMPS
+    stamp(a.stamps, 0);
+#endif
     const LaneTables lt   = load_lane_tables(a.crc_tab, lane);
     // preamble weights of this lane (see the candidate loop)
     const int tl = lane & 15, rw = lane >> 4;
@@ -468,6 +472,9 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     if (next < wr.end) ahead = grab_chunk(a, wr, lane);
     }
     flush_records();
+#ifdef ADSB_AMD_STAMPS
+    stamp(a.stamps, 1);
+#endif
 }
 
 } // namespace
@@ -478,12 +485,13 @@ uint32_t chunks_per_buffer_2400(uint32_t buf_samples)
     return (buf_samples - (uint32_t)kSpan24 + (uint32_t)kChunk - 1) / (uint32_t)kChunk;
 }
 
-hipError_t launch_scan2400(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream)
+hipError_t launch_scan2400(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start, hipEvent_t stop)
 {
     if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
     // persistent single-wave workgroups, as many as the LDS lets a CU hold (16 x 10 208 bytes), in whole (XCD, sub-range) units
     const uint32_t grid = scan_grid(a);
-    hipLaunchKernelGGL(scan2400_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
+    if (start && stop) hipExtLaunchKernelGGL(scan2400_kernel, dim3(grid), dim3(64), 0, stream, start, stop, 0, a, total_and_overflow);
+    else hipLaunchKernelGGL(scan2400_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
     return hipGetLastError();
 }
 

@@ -270,6 +270,20 @@ __device__ __forceinline__ void flush_records() { asm volatile("s_dcache_wb" :::
 __device__ __forceinline__ bool df_is_long(uint32_t df) { return df == 16 || df == 17 || df == 19 || df == 20 || df == 21; }
 __device__ __forceinline__ bool df_is_ap(uint32_t df) { return df == 0 || df == 4 || df == 5 || df == 16 || df == 20 || df == 21 || df == 24; }
 
+// Diagnostic builds only (-DADSB_AMD_STAMPS, tools/stamps.py): when every workgroup of a kernel came in and went out, on the constant
+// 100 MHz clock -- a time line of the stream without a profiler attached.  One plain store per wave and event into a slot of its own
+// (the host takes minimum and maximum: atomics on one word from 4096 waves cost the scan 70 us).
+constexpr uint32_t kStampGroups = 8192; // workgroups a launch may have in a diagnostic build
+__device__ __forceinline__ void stamp(unsigned long long* st, uint32_t which)
+{
+#ifdef ADSB_AMD_STAMPS
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); // every wave for itself
+    if (st && (threadIdx.x & 63u) == 0 && w < kStampGroups) st[(size_t)which * kStampGroups + w] = (unsigned long long)wall_clock64();
+#else
+    (void)st, (void)which;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // chunk geometry, the raw window of a chunk in registers, and the work distribution of the persistent scan kernels
 // ------------------------------------------------------------------------------------------------
