@@ -34,7 +34,10 @@ def build_hip(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # host side: x86-64-v3 (AVX2/FMA class: inline floor/round) with contraction off, so that the double arithmetic of the CPR and
     # field decoding rounds exactly like the expressions as written (the oracle is built the same way)
+    # -amdgpu-atomic-optimizer-strategy=None: the scan kernels issue their one-lane atomics themselves and read a ticket's value half a
+    # chunk after issuing it; the compiler's wave-aggregation of atomics wraps them in a sequence that waits for the value on the spot
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared", "-Wall", "-Wextra", "-march=x86-64-v3", "-ffp-contract=off",
+           "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + [os.path.join(CSRC, s) for s in HIP_SOURCES]
     if verbose:
         print(" ".join(cmd))

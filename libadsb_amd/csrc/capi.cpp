@@ -212,6 +212,9 @@ int make_args(adsb_amd_ctx* c, const void* iq_device, size_t nbytes, size_t buff
     std::memset(a, 0, sizeof(*a));
     a->iq             = static_cast<const uint8_t*>(iq_device);
     a->buf_stride     = bb;
+#ifdef ADSB_AMD_DIAG_ALIAS // diagnostic builds: every buffer is the first one again (the scan's arithmetic without its memory traffic)
+    a->buf_stride = 0;
+#endif
     a->buf_samples    = (uint32_t)(bb / 2);
     a->nbuf           = (uint32_t)nbuf;
     a->chunks_per_buf = c->mode == ADSB_AMD_MODE_2400 ? chunks_per_buffer_2400(a->buf_samples) : chunks_per_buffer(a->buf_samples);

@@ -476,11 +476,9 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
     uint32_t        chunk = wr.first + wr.slot;
     if (chunk >= wr.end) return;
     const uint32_t end = wr.end, nslot = wr.nslot;
-    constexpr uint32_t kGrab = 1;
-    auto grab = [&]() -> uint32_t { return grab_chunk(a, wr, lane); };
-    uint32_t  next    = chunk + nslot;
-    uint32_t  group   = grab(); // first chunk of the group grabbed last; its chunks are handed out one by one
-    uint32_t  in_group = 0;
+    uint32_t  next  = chunk + nslot;
+    uint32_t  group = grab_chunk(a, wr, lane); // the work item after `next`
+    Pending   pend{};                          // the previous chunk's directory entry and sums, not yet written (scan_common.hip.h)
     ChunkGeom g     = chunk_geom_of(a, wr.chunk_of(chunk), kFrameSpan);
     RawWindow raw;
     load_window<kHalo, false, true>(g, lane, raw);
@@ -529,12 +527,20 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         // ---------------- prefetch: the next chunk's loads fly while this chunk is processed
         const ChunkGeom cur = g;
         const uint32_t  me  = wr.chunk_of(chunk);
+        // control traffic first -- the previous chunk's directory entry and sums, the ticket for the work item after `group` --, the loads
+        // behind it: what the wait at the top of the next trip covers was all issued a chunk's time before
+        publish(a, pend, lane);
+        uint32_t ticket = 0;
+        if (group < end) ticket = grab_issue(a, wr, lane);
         if (next < end)
         {
             g = chunk_geom_of(a, wr.chunk_of(next), kFrameSpan);
             load_window<kHalo, false, true>(g, lane, raw);
             // (Touching the chunk after that one into the caches -- one dword per 64 bytes, two chunks ahead, so that the memory system has
-            // requests while the wave computes -- was tried: the kernel went from 0.212 to 0.32 ms; profiles/r03_sweep.txt.)
+            // requests while the wave computes -- was tried: the kernel went from 0.212 to 0.32 ms; profiles/r03_sweep.txt.  So was issuing
+            // these loads row by row inside the image build, each into the register the build has just consumed -- a quarter of a chunk's
+            // time earlier, for no register: 0.2155 -> 0.2260 ms; nine loads back to back are one 8.5 KB burst to the memory, four pairs
+            // 0.3 us apart are not; profiles/r04_sweep.txt.)
         }
         wave_lds_fence();
 
@@ -692,17 +698,14 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
             }
             wave_lds_fence();
         }
-        publish_count(a, me, e, lane, &logged);
+        pend = finish_chunk(me, e, &logged);
 
         if (next >= end) break;
         chunk = next;
-        next  = group + in_group;
-        if (++in_group == kGrab)
-        {
-            in_group = 0;
-            if (next < end) group = grab();
-        }
+        next  = group;
+        if (next < end) group = grab_value(wr, ticket);
     }
+    publish(a, pend, lane);
     flush_records();
 #ifdef ADSB_AMD_STAMPS
     stamp(a.stamps, 1);

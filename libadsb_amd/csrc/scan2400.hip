@@ -245,6 +245,7 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     RawWindow raw;
     load_window<kHalo24>(g, lane, raw);
     uint32_t logged = 0; // records in this wave's log (ScanArgs::log_cap)
+    Pending  pend{};     // the previous chunk's directory entry and sums, not yet written (scan_common.hip.h)
 
     for (;;)
     {
@@ -273,6 +274,10 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
 
     // ---------------- prefetch: the next chunk's loads fly while this chunk is processed
     const uint32_t me = wr.chunk_of(chunk), g0 = g.g0, npos = g.npos;
+    // control traffic (the previous chunk's directory entry and sums, the ticket for the work item after `ahead`) in front of the loads
+    publish(a, pend, lane);
+    uint32_t ticket = 0;
+    if (ahead < wr.end) ticket = grab_issue(a, wr, lane);
     if (next < wr.end)
     {
         g = chunk_geom_of(a, wr.chunk_of(next), kSpan24);
@@ -344,12 +349,12 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     {
         Emit e  = begin_chunk(a, me, logged);
         e.count = (surv == 0x123456789ull) ? 1 : 0; // keeps the gate alive
-        publish_count(a, me, e, lane, &logged);
+        pend    = finish_chunk(me, e, &logged);
     }
     if (next >= wr.end) break;
     chunk = next;
     next  = ahead;
-    if (next < wr.end) ahead = grab_chunk(a, wr, lane);
+    if (next < wr.end) ahead = grab_value(wr, ticket);
     continue;
 #endif
     const uint32_t mine = (uint32_t)__builtin_popcountll(surv);
@@ -464,13 +469,14 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
         wave_lds_fence();
         base = next_base;
     }
-    publish_count(a, me, e, lane, &logged);
+    pend = finish_chunk(me, e, &logged);
 
     if (next >= wr.end) break;
     chunk = next;
     next  = ahead;
-    if (next < wr.end) ahead = grab_chunk(a, wr, lane);
+    if (next < wr.end) ahead = grab_value(wr, ticket);
     }
+    publish(a, pend, lane);
     flush_records();
 #ifdef ADSB_AMD_STAMPS
     stamp(a.stamps, 1);

@@ -439,18 +439,36 @@ __device__ __forceinline__ Emit begin_chunk(const ScanArgs& a, uint32_t me, uint
     return e;
 }
 
-__device__ __forceinline__ void publish_count(const ScanArgs& a, uint32_t chunk, const Emit& e, int lane, uint32_t* logged)
+// What a finished chunk leaves for the ordering pass (wave-uniform).  It is written out (publish) half a chunk LATER, just in front of
+// the next prefetch: a wave waits for its prefetched window with s_waitcnt vmcnt(0) at the top of every trip, vector-memory operations
+// complete in issue order, and a store or an atomic issued at the end of a trip -- acknowledged by the memory side a microsecond or two
+// later -- made that wait cover them (profiles/r04_sweep.txt).  In front of the prefetch they are older than the loads the wait is for.
+struct Pending
 {
-    const uint32_t count = e.count, kept = count < e.cap ? count : e.cap;
-    *logged += kept;
+    uint32_t chunk, start, kept;
+    bool     over, valid;
+};
+__device__ __forceinline__ Pending finish_chunk(uint32_t chunk, const Emit& e, uint32_t* logged)
+{
+    Pending p;
+    p.chunk = chunk;
+    p.start = e.start;
+    p.kept  = e.count < e.cap ? e.count : e.cap;
+    p.over  = e.count > e.cap;
+    p.valid = true;
+    *logged += p.kept;
+    return p;
+}
+__device__ __forceinline__ void publish(const ScanArgs& a, const Pending& p, int lane)
+{
     // Vector atomics, one lane: they are performed where all XCDs see them.  The scalar unit's atomics (s_atomic_add) would save the six
     // vector instructions this costs, but they act on the issuing XCD's L2 only -- tools/isa_probe.hip loses additions from different XCDs
     // to one word -- and a group of kOrderChunks chunks may straddle two XCD ranges.
-    if (lane != 0) return;
-    *reinterpret_cast<uint2*>(a.chunk_dir + 2ull * chunk) = make_uint2(e.start, kept);
-    uint32_t* sum = a.block_sums + (chunk / kOrderChunks) * kSumStride;
-    if (count) atomicAdd(sum, kept);
-    if (count > e.cap) atomicOr(sum + 1, 1u);
+    if (!p.valid || lane != 0) return;
+    *reinterpret_cast<uint2*>(a.chunk_dir + 2ull * p.chunk) = make_uint2(p.start, p.kept);
+    uint32_t* sum = a.block_sums + (p.chunk / kOrderChunks) * kSumStride;
+    if (p.kept) atomicAdd(sum, p.kept);
+    if (p.over) atomicOr(sum + 1, 1u);
 }
 
 // Chunk order.  Workgroups b and b + nxcd share an XCD (round-robin dispatch).  The chunks are dealt out in groups of 16
@@ -503,12 +521,20 @@ __device__ __forceinline__ WorkRange work_range(const ScanArgs& a)
     w.end = nv;
     return w;
 }
-__device__ __forceinline__ uint32_t grab_chunk(const ScanArgs& a, const WorkRange& w, int lane)
+// Taking the next work item is two steps for the same reason as Pending: the atomic is issued in front of the prefetch (grab_issue,
+// the ticket stays in a vector register of lane 0), its value is read at the end of the trip (grab_value).  (The library is built with
+// -amdgpu-atomic-optimizer-strategy=None: the compiler's wave-aggregation of atomics reads the value back on the spot.)
+__device__ __forceinline__ uint32_t grab_issue(const ScanArgs& a, const WorkRange& w, int lane)
 {
     uint32_t v = 0;
     if (lane == 0) v = atomicAdd(&a.work_counters[w.range * 32u], 1u);
-    return w.first + 2u * w.nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    return v;
 }
+__device__ __forceinline__ uint32_t grab_value(const WorkRange& w, uint32_t ticket)
+{
+    return w.first + 2u * w.nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+}
+__device__ __forceinline__ uint32_t grab_chunk(const ScanArgs& a, const WorkRange& w, int lane) { return grab_value(w, grab_issue(a, w, lane)); }
 
 } // namespace
 } // namespace adsb_amd
