@@ -152,7 +152,13 @@ def bind_near_gpu(torch, local_rank):
             cpus.update(range(int(lo), int(hi or lo) + 1))
         cpus &= os.sched_getaffinity(0)
         if cpus:
-            os.sched_setaffinity(0, cpus)
+            # every thread this process has by now (the HIP runtime's among them: sched_setaffinity(0, ..) moves the calling thread only);
+            # threads started later inherit the mask of the thread that starts them
+            for tid in os.listdir("/proc/self/task"):
+                try:
+                    os.sched_setaffinity(int(tid), cpus)
+                except OSError:
+                    pass
             return node
     except Exception:
         pass
@@ -177,8 +183,9 @@ def main():
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    args.numa_node = None
     if world > 1 and not args.rehearse_on_one_gpu:
-        bind_near_gpu(torch, local_rank)
+        args.numa_node = bind_near_gpu(torch, local_rank)
     dist = None
     if world > 1 or args.sharded_step_on_one_rank:
         import torch.distributed as dist_mod
@@ -473,7 +480,12 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
     BB = A.REF_BUFFER_BYTES
     nbuf_total = world * ((args.mib << 20) // BB)
     first, nbuf = shard_range(nbuf_total, rank, world)
-    ncpu = max(1, len(os.sched_getaffinity(0)) // world)
+    # threads for generating this rank's input: its share of the CPUs it may run on -- all of them divided by the ranks, or, once the rank
+    # is bound to its GPU's NUMA node, that node's divided by the ranks that share the node (taken as evenly spread over the nodes)
+    import glob
+    nodes = max(1, len(glob.glob("/sys/devices/system/node/node[0-9]*")))
+    sharing = world if getattr(args, "numa_node", None) is None else max(1, -(-world // nodes))
+    ncpu = max(1, len(os.sched_getaffinity(0)) // sharing)
     iq_host, injected = synth.fill_range(first, nbuf, nthreads=ncpu)
     d_iq = torch.from_numpy(iq_host).cuda()
     torch.cuda.synchronize()
@@ -533,8 +545,9 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
             with torch.cuda.stream(comm):
                 n = sc.fetch_device(slot, ng.records_ptr(step), cap, comm.cuda_stream, packed=True)
                 ev = comm.record_event()
-                compute.wait_event(ev)
-                return ng.gather(step, n, first, wait=False)
+                # (No compute.wait_event(ev): the next scan of this slot is submitted only after ng.flush() has waited for this event on
+                # the host -- run() below --, which is when the header is written too.  The wait on the stream cost every scan a packet.)
+                return ng.gather(step, n, first, wait=False, event=ev)
         rec = sc.fetch_packed(slot, copy=False)
         ng.host_records_view(step)[:len(rec)] = rec
         return ng.gather(step, len(rec), first, wait=False)
@@ -547,6 +560,8 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
         """rank 0 takes delivery of a step (shared segments: waits for the step's headers; record gather: already complete), optionally
         runs the sequential host half over it -- the per-rank parts one after the other, straight out of the shared segments --, and
         releases the step's segments (keep: copies the parts first).  Returns what was delivered."""
+        if ng is not None and rank != 0:
+            ng.flush()  # this rank's header of the step before (its copy finished during the scan submitted since)
         if out is None:
             return None
         wd.phase("take delivery", getattr(out, "step", -1))
@@ -570,6 +585,8 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
         wd.phase("submit", 0)
         sc.submit(d_iq.data_ptr(), nbytes, BB, compute.cuda_stream, 0)
         for i in range(1, steps):
+            if ng is not None:
+                ng.flush()  # the copy of this slot's last records (step i - 2) is done: its header goes out, the slot may be scanned into again
             sc.submit(d_iq.data_ptr(), nbytes, BB, compute.cuda_stream, i & 1)
             settle(prev, resolver)  # rank 0 takes (and releases) the step before, whose hand-over ran beside a scan
             prev = deliver((i - 1) & 1)
@@ -632,6 +649,21 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
     run1(args.steps)
     barrier()
     indep = time.perf_counter() - t1
+    sharded_over_plain = None
+    if args.sharded_step_on_one_rank:
+        # the two loops in alternation, best window of each: what the hand-over costs a step, with the part's clock drift out of it
+        best_s = best_p = 1e9
+        for _ in range(3):
+            barrier()
+            t1 = time.perf_counter()
+            run(args.steps)
+            barrier()
+            best_s = min(best_s, time.perf_counter() - t1)
+            t1 = time.perf_counter()
+            run1(args.steps)
+            barrier()
+            best_p = min(best_p, time.perf_counter() - t1)
+        sharded_over_plain = round(best_p / best_s, 4)
 
     dev = "cuda" if on_device else "cpu"
     wd.phase("final reductions")
@@ -691,6 +723,7 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
                                   "all": [round(x, 4) for x in per_rank]},
             "independent_shards_value": round(samples_all * args.steps / indep / 1e6, 1),
             "record_transports_agree": transports_agree,
+            "sharded_over_plain": sharded_over_plain,
             "gather_bytes_per_step": int(nrec * 32),
         }
     if ng is not None:
@@ -869,8 +902,18 @@ def bench_uat978_one_stream(args, rank, local_rank, world, dist, A, synth, torch
             wd.phase("waiting for the rank before")
             dist.recv(word, src=rank - 1)
             at = int(word.item())
+            if at < 0:  # a rank before this one failed: pass the word on and stop at once (nobody sits in recv until a watchdog fires)
+                if rank < world - 1:
+                    dist.send(word, dst=rank + 1)
+                raise RuntimeError("rank %d: the part of an earlier rank failed" % rank)
         wd.phase("part finish")
-        frames, exit_local, done = u.part_finish(b - w0, e - w0, max(at - w0 // 2, 0), last, offset=w0, collect=collect)
+        try:
+            frames, exit_local, done = u.part_finish(b - w0, e - w0, max(at - w0 // 2, 0), last, offset=w0, collect=collect)
+        except Exception:
+            if rank < world - 1:
+                word[0] = -1
+                dist.send(word, dst=rank + 1)
+            raise
         if rank < world - 1:
             word[0] = exit_local + w0 // 2
             dist.send(word, dst=rank + 1)
@@ -902,7 +945,7 @@ def bench_uat978_one_stream(args, rank, local_rank, world, dist, A, synth, torch
         out = {"value": round(n_total * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                "steps": args.steps, "samples_in_the_stream": int(n_total), "frames": int(c[0].item()), "consumed": int(c[1].item()),
                "note": "one process_buffer over the whole stream per step; every rank's search and demodulation in parallel, the decisions rank after rank"}
-        if args.rehearse_on_one_gpu and n_total < (1 << 30):
+        if n_total < (1 << 30):
             # small enough for one call on this GPU: the same stream, whole
             whole = np.concatenate([synth.fill978(k, piece, cfg) for k in range(world * npieces)])
             wdev = torch.from_numpy(whole).cuda()

@@ -88,7 +88,9 @@ struct adsb_amd_ctx
     unsigned long long* stamps_d = nullptr; // diagnostic builds: four clock values per launch, a ring of kStampSteps launches
     unsigned            stamp_no = 0;
 #endif
-    bool        logs_ok = true; // raw records go to per-wave logs (false once a log has overflowed: per-chunk regions from then on)
+    bool        logs_ok = false; // raw records go to per-wave logs instead of per-chunk regions: ADSB_AMD_RECORD_LOGS=1.  Measured and not the
+                                 // default (profiles/r04_sweep.txt): the ordering pass reads the logs no faster once it has a lane per record, and
+                                 // the scan is 3 % slower with them (all waves' logs start at the same place modulo 32 KiB)
     std::string error;
 };
 
@@ -243,6 +245,12 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
         const uint64_t room = (uint64_t)s.args.total_chunks * s.cap_per_chunk;
         const uint32_t grid = s.args.total_chunks ? scan_grid(s.args) : 1u;
         s.args.log_cap      = (c->logs_ok && room < (1ull << 32)) ? (uint32_t)(room / grid) : 0u;
+#ifdef ADSB_AMD_LOG_SKEW // experiment: log starts that do not all fall on the same place modulo 32 KiB (a log is log_cap x 32 bytes: an odd number of 128-byte lines)
+        if (s.args.log_cap >= 64 && ((s.args.log_cap / 4) & 1u) == 0) s.args.log_cap -= 4;
+#endif
+#ifdef ADSB_AMD_LOG_CAP_MAX // experiment: a smaller footprint of the logs in the address space
+        if (s.args.log_cap > ADSB_AMD_LOG_CAP_MAX) s.args.log_cap = ADSB_AMD_LOG_CAP_MAX;
+#endif
     }
     s.args.work_counters = s.work_d;
     s.args.block_sums    = s.block_sums + (size_t)s.sums_phase * s.sums_words;
@@ -340,6 +348,7 @@ extern "C" int adsb_amd_create_mode(adsb_amd_ctx_t** out, int device, int mode)
     if ((e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->ctl_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     c->count_path = count_path_from_env();
+    if (const char* e = std::getenv("ADSB_AMD_RECORD_LOGS")) c->logs_ok = e[0] == '1'; // (A/B)
 
     uint32_t tab[112];
     build_crc_table(tab);
@@ -349,8 +358,8 @@ extern "C" int adsb_amd_create_mode(adsb_amd_ctx_t** out, int device, int mode)
     {
         if ((e = hipMalloc(&s.total_d, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(total)", e);
         if ((e = hipMemset(s.total_d, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(total)", e);
-        if ((e = hipMalloc(&s.work_d, kWorkCounters * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(work)", e);
-        if ((e = hipMemset(s.work_d, 0, kWorkCounters * 32 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(work)", e);
+        if ((e = hipMalloc(&s.work_d, kWorkCounters * kCounterStride * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(work)", e);
+        if ((e = hipMemset(s.work_d, 0, kWorkCounters * kCounterStride * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(work)", e);
         if ((e = hipHostMalloc(&s.total_h, sizeof(unsigned long long), hipHostMallocMapped)) != hipSuccess) return bail("hipHostMalloc(total)", e);
         *s.total_h = 0;
         if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&s.total_h_dev), s.total_h, 0)) != hipSuccess) return bail("hipHostGetDevicePointer(total)", e);
@@ -370,6 +379,14 @@ extern "C" int adsb_amd_create_mode(adsb_amd_ctx_t** out, int device, int mode)
 }
 
 #ifdef ADSB_AMD_STAMPS
+// diagnostic builds: every wave's clock values of one launch of the ring (4 x kStampGroups values: scan in, scan out, ordering pass in, out)
+extern "C" int adsb_amd_debug_stamps_raw(adsb_amd_ctx_t* c, unsigned launch, unsigned long long* out)
+{
+    if (!c || !out) return ADSB_AMD_EINVAL;
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(out, c->stamps_d + (size_t)4 * kStampGroups * (launch % kStampSteps), (size_t)4 * kStampGroups * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return ADSB_AMD_OK;
+}
 // diagnostic builds: per launch of the ring {scan first in, scan last out, ordering pass first in, last out} (0 where nothing was noted), and
 // how many launches there have been
 extern "C" int adsb_amd_debug_stamps(adsb_amd_ctx_t* c, unsigned long long* out /* kStampSteps x 4 */, unsigned* launches)
@@ -557,7 +574,8 @@ int fetch_slot(adsb_amd_ctx* c, Slot& s, unsigned what)
     }
     int rc = ensure_host(c, s, s.nrecords);
     if (rc) return rc;
-    if (s.nrecords)
+    static const bool diag_no_copy = std::getenv("ADSB_AMD_DIAG_NO_COPY") != nullptr; // measurements only: the scan without the record copy beside it
+    if (s.nrecords && !diag_no_copy)
     {
         if (c->count_path == kCountHost) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, s.ev_order, 0)); // the count comes from the pass's last workgroup, others may still be moving records
         if (what & ADSB_AMD_OUT_RECORDS)

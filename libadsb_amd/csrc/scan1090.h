@@ -14,7 +14,13 @@ namespace adsb_amd
 // of one reference buffer out of an LDS-staged window of kChunk + kHalo samples.
 constexpr int kLanes      = 64;
 constexpr int kRowSamples = 512; // one 16-byte load per lane = 8 IQ samples per lane = 512 per wavefront
-constexpr int kRows       = 8;   // 1 KiB load rows per chunk
+#ifndef ADSB_AMD_ROWS
+#define ADSB_AMD_ROWS 8
+#endif
+#ifndef ADSB_AMD_WAVES_PER_CU
+#define ADSB_AMD_WAVES_PER_CU 16
+#endif
+constexpr int kRows       = ADSB_AMD_ROWS; // 1 KiB load rows per chunk (experiments: 6 rows = 3072 positions let a CU hold 20 waves, profiles/r04_sweep.txt)
 constexpr int kChunk      = kRows * kRowSamples; // 4096 positions
 constexpr int kHalo       = 256;                 // >= 240 samples read past the last position, half a row
 constexpr int kFrameSpan  = 240;                 // (8 + 112) * 2 samples: reference loop bound (ADSB1090.cpp:772)
@@ -67,6 +73,10 @@ constexpr uint32_t kSumStride   = ADSB_AMD_SUM_STRIDE;  // words between entries
 constexpr uint32_t kSubRanges   = 4;  // work counters per XCD
 constexpr uint32_t kMaxXcd      = 16;
 constexpr uint32_t kWorkCounters = kSubRanges * kMaxXcd;
+#ifndef ADSB_AMD_COUNTER_STRIDE
+#define ADSB_AMD_COUNTER_STRIDE 32
+#endif
+constexpr uint32_t kCounterStride = ADSB_AMD_COUNTER_STRIDE; // words between work counters
 
 inline uint32_t chunks_per_buffer(uint32_t buf_samples)
 {
@@ -80,7 +90,7 @@ inline uint32_t chunks_per_buffer(uint32_t buf_samples)
 inline uint32_t scan_grid(const ScanArgs& a)
 {
     const uint32_t unit = a.nxcd * kSubRanges; // every (XCD, sub-range) gets the same number of waves
-    uint32_t       grid = (a.ncu * 16u / unit) * unit;
+    uint32_t       grid = (a.ncu * (uint32_t)ADSB_AMD_WAVES_PER_CU / unit) * unit;
     if (grid == 0) grid = unit;
     if (grid > a.total_chunks) grid = ((a.total_chunks + unit - 1u) / unit) * unit;
     return grid;

@@ -445,6 +445,12 @@ __device__ __forceinline__ void queue_survivors(uint64_t surv, uint32_t first, i
     }
 }
 
+#ifdef ADSB_AMD_SPLIT_PREFETCH // experiment (profiles/r04_sweep.txt): the next window in two bursts, rows 0-3 behind the image build, the rest behind stage 1
+__device__ __forceinline__ uint4 load_row_at(const ChunkGeom& g, int k, int lane)
+{
+    return *reinterpret_cast<const uint4*>(g.buf + 2ull * g.g0 + (uint32_t)(k * kRowSamples * 2) + 16u * (uint32_t)lane);
+}
+#endif
 #ifndef ADSB_AMD_MIN_WAVES
 #define ADSB_AMD_MIN_WAVES 4
 #endif
@@ -472,14 +478,13 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
 
     // XCD-aware chunk order, one work counter per sub-range: scan_common.hip.h (WorkRange).  (Round 1 also offset the waves of a
     // SIMD in time at the start so that their phases would not coincide; with the priority hint below that costs 1.7 %.)
-    const WorkRange wr = work_range(a);
-    uint32_t        chunk = wr.first + wr.slot;
-    if (chunk >= wr.end) return;
-    const uint32_t end = wr.end, nslot = wr.nslot;
-    uint32_t  next  = chunk + nslot;
-    uint32_t  group = grab_chunk(a, wr, lane); // the work item after `next`
-    Pending   pend{};                          // the previous chunk's directory entry and sums, not yet written (scan_common.hip.h)
-    ChunkGeom g     = chunk_geom_of(a, wr.chunk_of(chunk), kFrameSpan);
+    WorkRange wr = work_range(a);
+    if (wr.slot >= wr.end) return;
+    // work items by their chunk number; a wave's first two are fixed, the rest come from its counter (later from others': take_next)
+    uint32_t chunk = wr.chunk_of(wr.slot);
+    uint32_t next  = wr.slot + wr.nslot < wr.end ? wr.chunk_of(wr.slot + wr.nslot) : kNoChunk;
+    Pending  pend{};                          // the previous chunk's directory entry and sums, not yet written (scan_common.hip.h)
+    ChunkGeom g     = chunk_geom_of(a, chunk, kFrameSpan);
     RawWindow raw;
     load_window<kHalo, false, true>(g, lane, raw);
     uint32_t logged = 0; // records in this wave's log (ScanArgs::log_cap)
@@ -526,15 +531,30 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
 
         // ---------------- prefetch: the next chunk's loads fly while this chunk is processed
         const ChunkGeom cur = g;
-        const uint32_t  me  = wr.chunk_of(chunk);
-        // control traffic first -- the previous chunk's directory entry and sums, the ticket for the work item after `group` --, the loads
-        // behind it: what the wait at the top of the next trip covers was all issued a chunk's time before
+        const uint32_t  me  = chunk;
+        // control traffic first -- the previous chunk's directory entry and sums, the ticket for the work item after `next` --, the loads
+        // behind it: what the wait at the top of the next trip covers was all issued a chunk's time before.  The ticket's value is read at
+        // the end of this trip, half a chunk's time from here.  (Until round 4 a wave held a third work item in reserve, taken a whole trip
+        // before its prefetch: a wave that drew one of its counter's last tickets then still had three chunks to go while its neighbours ran
+        // dry, and the waves of a launch ended 30 us apart, 18 us idle on average; profiles/r04_sweep.txt.)
         publish(a, pend, lane);
         uint32_t ticket = 0;
-        if (group < end) ticket = grab_issue(a, wr, lane);
-        if (next < end)
+        if (next != kNoChunk) ticket = grab_issue(a, wr, lane);
+#ifdef ADSB_AMD_SPLIT_PREFETCH
+        bool split = false;
+#endif
+        if (next != kNoChunk)
         {
-            g = chunk_geom_of(a, wr.chunk_of(next), kFrameSpan);
+            g = chunk_geom_of(a, next, kFrameSpan);
+#ifdef ADSB_AMD_SPLIT_PREFETCH
+            split = g.g0 + (uint32_t)(kChunk + kHalo) <= g.n;
+            if (split)
+            {
+#pragma unroll
+                for (int k = 0; k < kRows / 2; k++) raw.row[k] = load_row_at(g, k, lane);
+            }
+            else
+#endif
             load_window<kHalo, false, true>(g, lane, raw);
             // (Touching the chunk after that one into the caches -- one dword per 64 bytes, two chunks ahead, so that the memory system has
             // requests while the wave computes -- was tried: the kernel went from 0.212 to 0.32 ms; profiles/r03_sweep.txt.  So was issuing
@@ -596,6 +616,15 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         }
         // bit n of surv: the half at index 1024 (n >> 4) + 16 lane + (n & 15) of the image (tile_index of its position)
         uint64_t surv = (uint64_t)surv32[0] | ((uint64_t)surv32[1] << 32);
+#ifdef ADSB_AMD_SPLIT_PREFETCH
+        if (split)
+        {
+#pragma unroll
+            for (int k = kRows / 2; k < kRows; k++) raw.row[k] = load_row_at(g, k, lane);
+            raw.cont_hi = *reinterpret_cast<const uint2*>(g.buf + 2ull * g.g0 + 2u * (uint32_t)kChunk + 8u * (uint32_t)lane);
+            raw.front   = 0x7F7Fu;
+        }
+#endif
         // The rest of the chunk is short dependent chains (scalar work, LDS round trips, a few vector operations at a time); the other
         // waves of the SIMD are mostly in the vector-dense image and stage-1 phases.  With raised priority these chains issue as soon as
         // they are ready instead of queueing behind that work, the wave is back in a dense phase sooner, and the vector unit idles less:
@@ -682,7 +711,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
                     const int      src = __builtin_ctzll(mk);
                     mk &= mk - 1ull;
                     const uint32_t a0  = (uint32_t)__builtin_amdgcn_readlane((int)ti, src);
-                    const uint32_t pos = (a0 >> 1) | ((a0 & 1u) << 11);
+                    const uint32_t pos = (a0 >> 1) + (a0 & 1u) * (uint32_t)kHalfChunk;
                     Win            w;
                     w.a0  = a0;
                     // the sample in front of position 0 is the one in front of the chunk; the one in front of position 2048 is the last low half
@@ -700,10 +729,9 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         }
         pend = finish_chunk(me, e, &logged);
 
-        if (next >= end) break;
+        if (next == kNoChunk) break;
         chunk = next;
-        next  = group;
-        if (next < end) group = grab_value(wr, ticket);
+        next  = take_next(a, wr, ticket, lane);
     }
     publish(a, pend, lane);
     flush_records();
@@ -808,7 +836,7 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
     // than this one) and the work counters start from zero
     for (uint32_t k = blockIdx.x * kOrderThreads + tid; k < 2u * next_entries; k += nblocks * kOrderThreads)
         next_block_sums[(k >> 1) * kSumStride + (k & 1u)] = 0;
-    if (blockIdx.x == 0 && tid < kWorkCounters) work_counters[tid * 32u] = 0;
+    if (blockIdx.x == 0 && tid < kWorkCounters) work_counters[tid * kCounterStride] = 0;
     if (tid == 0 && block_sums[blockIdx.x * kSumStride + 1]) atomicOr(&total_overflow[1], 1u); // some chunk of this block overflowed its region
     // records in earlier blocks, and this block's chunk counts
     uint32_t before = 0;

@@ -236,12 +236,11 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     if (blockIdx.x == 0 && lane < 2) total_overflow[lane] = 0; // {record total, overflow flag}: filled by the ordering pass that follows in-stream
 
     // persistent waves, chunk order and work counters as in scan1090_kernel (scan_common.hip.h)
-    const WorkRange wr    = work_range(a);
-    uint32_t        chunk = wr.first + wr.slot;
-    if (chunk >= wr.end) return;
-    uint32_t  next  = chunk + wr.nslot;
-    uint32_t  ahead = grab_chunk(a, wr, lane);
-    ChunkGeom g     = chunk_geom_of(a, wr.chunk_of(chunk), kSpan24);
+    WorkRange wr = work_range(a);
+    if (wr.slot >= wr.end) return;
+    uint32_t  chunk = wr.chunk_of(wr.slot);
+    uint32_t  next  = wr.slot + wr.nslot < wr.end ? wr.chunk_of(wr.slot + wr.nslot) : kNoChunk;
+    ChunkGeom g     = chunk_geom_of(a, chunk, kSpan24);
     RawWindow raw;
     load_window<kHalo24>(g, lane, raw);
     uint32_t logged = 0; // records in this wave's log (ScanArgs::log_cap)
@@ -273,14 +272,14 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     if (lane == 0) img16[2 * (kImgBase - 1)] = (uint16_t)iq1_to_s(raw.front & 0xFFu, raw.front >> 8);
 
     // ---------------- prefetch: the next chunk's loads fly while this chunk is processed
-    const uint32_t me = wr.chunk_of(chunk), g0 = g.g0, npos = g.npos;
-    // control traffic (the previous chunk's directory entry and sums, the ticket for the work item after `ahead`) in front of the loads
+    const uint32_t me = chunk, g0 = g.g0, npos = g.npos;
+    // control traffic (the previous chunk's directory entry and sums, the ticket for the work item after `next`) in front of the loads
     publish(a, pend, lane);
     uint32_t ticket = 0;
-    if (ahead < wr.end) ticket = grab_issue(a, wr, lane);
-    if (next < wr.end)
+    if (next != kNoChunk) ticket = grab_issue(a, wr, lane);
+    if (next != kNoChunk)
     {
-        g = chunk_geom_of(a, wr.chunk_of(next), kSpan24);
+        g = chunk_geom_of(a, next, kSpan24);
         load_window<kHalo24>(g, lane, raw);
     }
     wave_lds_fence();
@@ -351,10 +350,9 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
         e.count = (surv == 0x123456789ull) ? 1 : 0; // keeps the gate alive
         pend    = finish_chunk(me, e, &logged);
     }
-    if (next >= wr.end) break;
+    if (next == kNoChunk) break;
     chunk = next;
-    next  = ahead;
-    if (next < wr.end) ahead = grab_value(wr, ticket);
+    next  = take_next(a, wr, ticket, lane);
     continue;
 #endif
     const uint32_t mine = (uint32_t)__builtin_popcountll(surv);
@@ -471,10 +469,9 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     }
     pend = finish_chunk(me, e, &logged);
 
-    if (next >= wr.end) break;
+    if (next == kNoChunk) break;
     chunk = next;
-    next  = ahead;
-    if (next < wr.end) ahead = grab_value(wr, ticket);
+    next  = take_next(a, wr, ticket, lane);
     }
     publish(a, pend, lane);
     flush_records();

@@ -374,7 +374,7 @@ __device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWin
       // wave-uniform base plus a 32-bit lane offset that never changes, so the loads take the base from scalar registers and no
       // vector instruction is spent on addresses.  Lanes beyond the halo repeat the halo's loads (their copy is never used) instead
       // of being masked off and zeroed.
-        static_assert(kRows == 8 && kRowSamples * 2 == 1024, "the row offsets below assume 1 KiB rows, four per 4 KiB base");
+        static_assert(kRows <= 8 && kRowSamples * 2 == 1024, "the row offsets below assume 1 KiB rows, four per 4 KiB base");
         // Three scalar bases 4 KiB apart (a load's immediate offset reaches 4095) pinned to scalar registers, and explicitly global
         // pointers rebuilt from them (an integer that went through a register constraint has forgotten its address space).
         typedef const __attribute__((address_space(1))) uint8_t* gptr_t;
@@ -382,7 +382,7 @@ __device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWin
         typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
         typedef const __attribute__((address_space(1))) u32x4_t* gvec_t;
         typedef const __attribute__((address_space(1))) u32x2_t* gvec2_t;
-        uint64_t b0 = reinterpret_cast<uint64_t>(g.buf) + 2ull * g.g0, b1 = b0 + 4096u, b2 = b0 + 8192u;
+        uint64_t b0 = reinterpret_cast<uint64_t>(g.buf) + 2ull * g.g0, b1 = b0 + 4096u, b2 = b0 + 2u * (uint32_t)kChunk;
         asm("" : "+s"(b0), "+s"(b1), "+s"(b2));
         const uint32_t off = 16u * (uint32_t)lane, off_halo = 16u * ((uint32_t)lane % (uint32_t)(HALO / 8));
 #pragma unroll
@@ -467,8 +467,10 @@ __device__ __forceinline__ void publish(const ScanArgs& a, const Pending& p, int
     if (!p.valid || lane != 0) return;
     *reinterpret_cast<uint2*>(a.chunk_dir + 2ull * p.chunk) = make_uint2(p.start, p.kept);
     uint32_t* sum = a.block_sums + (p.chunk / kOrderChunks) * kSumStride;
+#ifndef ADSB_AMD_DIAG_NO_SUMS // diagnostic builds (wrong results): what do the per-chunk additions cost?
     if (p.kept) atomicAdd(sum, p.kept);
     if (p.over) atomicOr(sum + 1, 1u);
+#endif
 }
 
 // Chunk order.  Workgroups b and b + nxcd share an XCD (round-robin dispatch).  The chunks are dealt out in groups of 16
@@ -491,34 +493,49 @@ struct WorkRange
     uint32_t range;      // which counter
     uint32_t xcd, sub, nxcd;
     uint32_t glog;       // log2 of the group size (ScanArgs::group_log2)
+#ifdef ADSB_AMD_DIAG_NO_GRAB
+    uint32_t diag_k = 0;
+#endif
     __device__ __forceinline__ uint32_t chunk_of(uint32_t v) const
     {
         const uint32_t gi = (v >> glog) * kSubRanges + sub; // group index inside the XCD
         return (((gi * nxcd + xcd) << glog) | (v & ((1u << glog) - 1u)));
     }
 };
+// The share of counter (xcd, sub): how many virtual indices it has (its end) -- groups gg = gi * nxcd + xcd < TG with gi % kSubRanges == sub,
+// the recording's last group may be short.
+__device__ __forceinline__ void range_share(const ScanArgs& a, WorkRange& w, uint32_t xcd, uint32_t sub)
+{
+    const uint32_t nxcd = a.nxcd;
+    w.nxcd              = nxcd;
+    w.xcd               = xcd;
+    w.sub               = sub;
+    w.range             = xcd * kSubRanges + sub;
+    w.first             = 0;
+    w.glog              = a.group_log2;
+    const uint32_t gsz  = 1u << w.glog;
+    const uint32_t tg   = (a.total_chunks + gsz - 1) >> w.glog;
+    const uint32_t cx   = tg / nxcd + (xcd < tg % nxcd ? 1u : 0u);                 // groups of this XCD
+    const uint32_t ng   = cx > sub ? (cx - sub + kSubRanges - 1) / kSubRanges : 0u; // of this counter
+    uint32_t       nv   = ng << w.glog;
+    const uint32_t tail = a.total_chunks - ((tg - 1) << w.glog);                   // chunks of the last group (tg >= 1: the launch has work)
+    if (ng && tail < gsz && (tg - 1) % nxcd == xcd && ((tg - 1) / nxcd) % kSubRanges == sub) nv -= gsz - tail;
+    w.end = nv;
+}
 __device__ __forceinline__ WorkRange work_range(const ScanArgs& a)
 {
     WorkRange      w;
     const uint32_t nxcd = a.nxcd;
-    w.nxcd              = nxcd;
-    w.xcd               = blockIdx.x % nxcd;
     const uint32_t wg   = blockIdx.x / nxcd; // index of this workgroup among those of its XCD
-    w.sub               = wg % kSubRanges;
-    w.slot              = wg / kSubRanges;
     w.nslot             = gridDim.x / (nxcd * kSubRanges); // the grid is a multiple of nxcd * kSubRanges
-    w.range             = w.xcd * kSubRanges + w.sub;
-    w.first             = 0;
-    // how many chunks fall to this counter: groups gg = gi * nxcd + xcd < TG with gi % kSubRanges == sub, the recording's last group may be short
-    w.glog              = a.group_log2;
-    const uint32_t gsz  = 1u << w.glog;
-    const uint32_t tg   = (a.total_chunks + gsz - 1) >> w.glog;
-    const uint32_t cx   = tg / nxcd + (w.xcd < tg % nxcd ? 1u : 0u);               // groups of this XCD
-    const uint32_t ng   = cx > w.sub ? (cx - w.sub + kSubRanges - 1) / kSubRanges : 0u; // of this counter
-    uint32_t       nv   = ng << w.glog;
-    const uint32_t tail = a.total_chunks - ((tg - 1) << w.glog);                   // chunks of the last group (tg >= 1: the launch has work)
-    if (ng && tail < gsz && (tg - 1) % nxcd == w.xcd && ((tg - 1) / nxcd) % kSubRanges == w.sub) nv -= gsz - tail;
-    w.end = nv;
+#ifdef ADSB_AMD_MIXED_COUNTERS // experiment (profiles/r04_sweep.txt): every counter is served by waves of ALL XCDs, so a slow XCD simply draws fewer tickets
+    const uint32_t nranges = nxcd * kSubRanges, r = wg % nranges;
+    w.slot                 = (wg / nranges) * nxcd + blockIdx.x % nxcd;
+    range_share(a, w, r / kSubRanges, r % kSubRanges);
+#else
+    w.slot = wg / kSubRanges;
+    range_share(a, w, blockIdx.x % nxcd, wg % kSubRanges);
+#endif
     return w;
 }
 // Taking the next work item is two steps for the same reason as Pending: the atomic is issued in front of the prefetch (grab_issue,
@@ -527,7 +544,11 @@ __device__ __forceinline__ WorkRange work_range(const ScanArgs& a)
 __device__ __forceinline__ uint32_t grab_issue(const ScanArgs& a, const WorkRange& w, int lane)
 {
     uint32_t v = 0;
-    if (lane == 0) v = atomicAdd(&a.work_counters[w.range * 32u], 1u);
+#ifdef ADSB_AMD_DIAG_NO_GRAB // diagnostic builds: a ticket without memory traffic (every wave counts for itself: fixed stride inside its counter's share)
+    v = w.slot + w.nslot * const_cast<WorkRange&>(w).diag_k++;
+#else
+    if (lane == 0) v = atomicAdd(&a.work_counters[w.range * kCounterStride], 1u);
+#endif
     return v;
 }
 __device__ __forceinline__ uint32_t grab_value(const WorkRange& w, uint32_t ticket)
@@ -535,6 +556,63 @@ __device__ __forceinline__ uint32_t grab_value(const WorkRange& w, uint32_t tick
     return w.first + 2u * w.nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
 }
 __device__ __forceinline__ uint32_t grab_chunk(const ScanArgs& a, const WorkRange& w, int lane) { return grab_value(w, grab_issue(a, w, lane)); }
+
+// A work item as the scan loops carry it: the chunk's number in the recording, or kNoChunk.
+constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
+
+// The ticket drawn half a trip ago -> the chunk after `next`.  While the wave's counter has work that is its chunk_of(); when the counter
+// is dry the wave turns to another one's share for the rest of the launch (w then describes THAT counter: the tickets it draws from now on
+// are the victim's).  Why: the XCDs get equal shares but do not run equally fast -- the last wave of the fastest XCD left 205 us into a
+// launch, that of the slowest 228 us, which XCD is slow changes from launch to launch (profiles/r04_sweep.txt: waves out by XCD) -- and
+// the launch ends with its slowest XCD.  A thief reads all counters at once (lane c reads counter c: one load, L1 bypassed), works
+// out what each has left and draws from the one with the most (ties and near-ties broken by its own slot, so that the thieves spread).
+// A stale reading can only show MORE work than there is (counters only grow): a wasted draw, never a missed chunk.  Counters are only
+// ever advanced by agent-scope atomics, so any wave may draw from any of them; what is lost is the L2 hit on a stolen chunk's halo.
+// (First version: a shared word of "dry" bits, read and written by every thief with a returning atomic -- 4096 waves on one word at
+// the end of a launch cost more than the imbalance: 0.211 -> 0.25 ms.)
+// Small inputs (group_log2 == 0: a live buffer) do not steal: a handful of chunks, and the probes would cost more than they balance.
+__device__ __forceinline__ uint32_t take_next(const ScanArgs& a, WorkRange& w, uint32_t ticket, int lane)
+{
+    const uint32_t v = grab_value(w, ticket);
+    if (v < w.end) return w.chunk_of(v);
+#if !defined(ADSB_AMD_STEAL) || !ADSB_AMD_STEAL
+    (void)a, (void)lane;
+    return kNoChunk; // measured and not kept (profiles/r04_sweep.txt): with the stealing below the kernel took 0.24-0.28 ms instead of 0.211
+#else
+    if (a.group_log2 == 0) return kNoChunk;
+    const uint32_t nranges = a.nxcd * kSubRanges;
+    for (uint32_t tries = 0; tries < 4u; tries++)
+    {
+        uint32_t key = 0;
+        if ((uint32_t)lane < nranges)
+        {
+            WorkRange mine = w;
+            range_share(a, mine, (uint32_t)lane / kSubRanges, (uint32_t)lane % kSubRanges);
+            const uint32_t drawn = __hip_atomic_load(&a.work_counters[(uint32_t)lane * kCounterStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t taken = 2u * w.nslot + drawn;
+            const uint32_t left  = mine.end > taken ? mine.end - taken : 0u;
+            if (left) key = ((left < 0xFFFFu ? left : 0xFFFFu) >> 2 << 8) | ((((uint32_t)lane + w.slot) & 63u) << 2) | 1u; // most work first, in steps of four chunks
+        }
+        uint32_t best = 0;
+        for (uint32_t c = 0; c < nranges; c++)
+        {
+            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)c);
+            best             = k > best ? k : best;
+        }
+        if (best == 0) return kNoChunk;
+        const uint32_t victim = (uint32_t)__builtin_ctzll(ballot(key == best));
+        WorkRange      w2     = w;
+        range_share(a, w2, victim / kSubRanges, victim % kSubRanges);
+        const uint32_t v2 = grab_chunk(a, w2, lane);
+        if (v2 < w2.end)
+        {
+            w = w2;
+            return w.chunk_of(v2);
+        }
+    }
+    return kNoChunk;
+#endif
+}
 
 } // namespace
 } // namespace adsb_amd

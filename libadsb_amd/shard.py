@@ -10,9 +10,12 @@ arrays to the rank that runs the sequential resolver -- RCCL over xGMI with back
                       32-byte header in front of the records, so there is no separate count exchange; on "nccl" the payload
                       goes device to device (the scanner copies its sorted records straight into the send buffer)
   NodeGather          the same result on one node without funnelling the records through the root's GPU: every rank's GPU writes
-                      its records over its own PCIe link into a page-locked segment of node-shared host memory, only the 32-byte
-                      headers are gathered (RCCL).  With RootGather the root's one host link carries N x 9 MB per GiB-step and
-                      bounds the job from N = 2 on; here it carries 9 MB whatever N is.
+                      its records over its own PCIe link into a page-locked segment of node-shared host memory; the 32-byte header
+                      of a step (count, first buffer, rank, step) is written by the rank's host thread into its slot of the shared
+                      control page once the copy's event has completed, and the root polls the slots -- no collective, no RCCL
+                      kernel beside the persistent scan (round 4; until then the headers were gathered over RCCL).  With
+                      RootGather the root's one host link carries N x 9 MB per GiB-step and bounds the job from N = 2 on; here it
+                      carries 9 MB whatever N is.
 """
 import mmap
 import os
@@ -133,13 +136,11 @@ class _PendingParts:
     """What NodeGather.gather(wait=False) returns on the root: result() waits for the step's headers (hence for every rank's
     copy) and returns the per-rank views."""
 
-    def __init__(self, owner, step, heads_h, event):
-        self.owner, self.step, self.heads_h, self.event = owner, step, heads_h, event
+    def __init__(self, owner, step):
+        self.owner, self.step = owner, step
 
     def result(self):
-        if self.event is not None:
-            self.event.synchronize()
-        return self.owner._views(self.step, self.heads_h.numpy())
+        return self.owner.collect(self.step)
 
 
 class NodeGather:
@@ -148,14 +149,17 @@ class NodeGather:
     One file in /dev/shm holds a control page and world x 2 page-aligned segments of cap records (two, so that the ranks can fill
     step k + 1 while the root still reads step k).  Every rank maps the file; a rank registers only ITS OWN two segments with the HIP
     runtime (they are the only ones its GPU writes: its scanner copies the step's records straight from HBM into `records_ptr(step)`
-    over its own PCIe link), the root reads the others through the plain mapping.  `gather(step, count, first_buffer)` then gathers
-    only a 32-byte header per rank (RCCL on "nccl", on the same stream as the copy, so a header that has arrived implies the records
-    have) and returns on the root one (records view, first buffer) pair per rank, in rank = recording order; the resolver consumes
-    them one after the other without a copy (`concatenate` makes one array with recording-wide buffer indices where one is wanted).
+    over its own PCIe link), the root reads the others through the plain mapping.  `gather(step, count, first_buffer, event=...)`
+    notes the step's 32-byte header (count, first buffer, rank, step); it is WRITTEN into the rank's slot of the control page by the
+    rank's host thread once `event` -- recorded on the stream behind the copy -- has completed (flush(): at the rank's next gather /
+    acquire, or when it is called), the step number last, so a header the root can see implies records it can see.  The root polls the
+    slots (collect(), bounded) and gets one (records view, first buffer) pair per rank, in rank = recording order; the resolver
+    consumes them one after the other without a copy (`concatenate` makes one array with recording-wide buffer indices where one is
+    wanted).  Nothing per step goes through torch.distributed: the collective that used to carry the headers put one RCCL kernel per
+    step beside the persistent scan kernel, about two of the four points the sharded step cost over the plain one.
 
-    Flow control is explicit: a segment of parity k & 1 is rewritten for step k + 2, and nothing in a header gather stops a rank from
-    running that far ahead (a 32-byte send can complete into the peer's FIFO before the root has posted its side).  The root therefore
-    publishes the last step it has finished READING in the control page (`release(step)`), and `acquire(step)` -- called by every
+    Flow control is explicit: a segment of parity k & 1 is rewritten for step k + 2, and nothing stops a rank from running that far
+    ahead.  The root therefore publishes the last step it has finished READING in the control page (`release(step)`), and `acquire(step)` -- called by every
     rank before it lets its GPU write the segment of `step` -- waits until step - 2 has been released (bounded: raises TimeoutError).
 
     Raises OSError at construction, on every rank, when the segment cannot be set up on any one of them (no /dev/shm space,
@@ -163,6 +167,8 @@ class NodeGather:
     """
 
     PAGE = 4096
+    _SLOT0, _SLOT = 16, 8  # control page as int64: [0] last step released; rank r's header of a step at [_SLOT0 + _SLOT * (2 r + (step & 1))]:
+    #                        count, first buffer, rank, step (two per rank like the segments: a rank may be a step ahead of the root's reading)
     _fail_rank_for_tests = None  # (rank, stage): that rank fails at that stage of the construction ("file", "map", "register")
 
     def __init__(self, cap_records, root=0, group=None, tag=None, acquire_timeout_s=120.0, dtype=RECORD_DTYPE):
@@ -172,6 +178,7 @@ class NodeGather:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.on_device = dist.get_backend(group) == "nccl"
         self.acquire_timeout_s = float(acquire_timeout_s)
+        assert self._SLOT0 + self._SLOT * 2 * self.world <= self.PAGE // 8, "the control page holds %d ranks' headers" % ((self.PAGE // 8 - self._SLOT0) // self._SLOT // 2)
         self.seg = -(-self.cap * REC // self.PAGE) * self.PAGE  # whole pages: a rank registers its segments alone
         total = self.PAGE + self.world * 2 * self.seg
         dev = torch.device("cuda", torch.cuda.current_device()) if self.on_device else torch.device("cpu")
@@ -220,6 +227,8 @@ class NodeGather:
                 self._ctl = self._np[:self.PAGE].view(np.int64)  # [0]: last step the root has finished reading, -1 before any
                 if self.rank == root:
                     self._ctl[0] = -1
+                for par in (0, 1):
+                    self._ctl[self._slot(self.rank, par) + 3] = -1  # no step posted yet
                 for step in (0, 1):  # first touch of this rank's own segments (on the NUMA node this rank runs on)
                     o = self._offset(self.rank, step)
                     self._np[o:o + self.seg] = 0
@@ -240,20 +249,29 @@ class NodeGather:
         if not int(ok.item()):
             self.close()
             raise OSError("node-shared record segment could not be set up on every rank")
-        # ring of page-locked header sources, see RootGather
-        self._hdrs_h = [torch.zeros(4, dtype=torch.int64).pin_memory() if self.on_device else torch.zeros(4, dtype=torch.int64) for _ in range(4)]
-        self._hdr = torch.zeros(4, dtype=torch.int64, device=dev)
-        # the gathered headers are the rows of one tensor (copied to the host in one piece, no stacking kernel per step)
-        self._parts2d = torch.zeros(self.world, 4, dtype=torch.int64, device=dev) if self.rank == root else None
-        self._parts = list(self._parts2d.unbind(0)) if self.rank == root else None
-        self._heads_h = [torch.zeros(self.world, 4, dtype=torch.int64).pin_memory() for _ in range(4)] if (self.rank == root and self.on_device) else None
-        self._events = [torch.cuda.Event() for _ in range(4)] if (self.rank == root and self.on_device) else None
+        self._posted = []  # headers noted but not yet written: (step, count, first buffer, event)
+        self.ranks_seen = 0
+
+    def _slot(self, rank, step):
+        return self._SLOT0 + self._SLOT * (2 * rank + (step & 1))
 
     def _offset(self, rank, step):
         return self.PAGE + (rank * 2 + (step & 1)) * self.seg
 
+    def flush(self):
+        """Write the headers noted so far into this rank's slot of the control page, oldest first, each once its event has completed
+        (waits for it: by the time this is called -- the rank's next step, or the end of a loop -- the copy is long done)."""
+        for step, count, first, event in self._posted:
+            if event is not None:
+                event.synchronize()
+            base = self._slot(self.rank, step)
+            self._ctl[base], self._ctl[base + 1], self._ctl[base + 2] = count, first, self.rank
+            self._ctl[base + 3] = step  # last: x86 stores become visible in program order, and the reader reads it first
+        self._posted = []
+
     def acquire(self, step):
         """Before this rank's segment of `step` is written: wait until the root has finished reading step - 2 (same segment)."""
+        self.flush()  # the header of the step before, if its copy has an event: the root may be waiting for it before it releases
         need = step - 2
         if need < 0 or int(self._ctl[0]) >= need:
             return
@@ -279,37 +297,44 @@ class NodeGather:
         o = self._offset(self.rank, step)
         return self._np[o:o + self.cap * REC].view(self.dtype)
 
-    def gather(self, step, count, first_buffer, wait=True):
-        """Collective; on "nccl" call it on the stream the records were copied on.  Returns on the root [(records, first_buffer)] per
-        rank (views of the shared segments, valid until release(step)), elsewhere None.  wait=False: the root gets a handle
-        whose result() gives the same once the step's headers have arrived -- so that it can enqueue step k + 1 before it looks at
-        step k, like the other ranks do.  The handle's ranks_seen is the number of headers that carried this step's number."""
+    def gather(self, step, count, first_buffer, wait=True, event=None):
+        """`count` records of this rank lie (or, with `event`, will lie once it has completed) in its segment of `step`.  Not a
+        collective.  Returns on the root [(records, first_buffer)] per rank (views of the shared segments, valid until
+        release(step)), elsewhere None.  wait=False: the root gets a handle whose result() gives the same once every rank's header
+        of the step is there -- so that it can enqueue step k + 1 before it looks at step k, like the other ranks do.  A rank that
+        passes an event (on "nccl" none given means: one recorded here, on the current stream) must come back (gather / acquire /
+        flush) for its header to be written."""
         if count > self.cap:
             raise RuntimeError("rank %d produced %d records, its segment holds %d" % (self.rank, count, self.cap))
-        src = self._hdrs_h[step & 3]
-        src[0], src[1], src[2], src[3] = int(count), int(first_buffer), int(step), int(self.rank)
-        self._hdr.copy_(src, non_blocking=True)
-        dist.gather(self._hdr, self._parts, dst=self.root, group=self.group)
+        if event is None and self.on_device:
+            event = torch.cuda.current_stream().record_event()  # the records were copied on the current stream (the documented use)
+        self._posted.append((int(step), int(count), int(first_buffer), event))
+        if event is None:
+            self.flush()
         if self.rank != self.root:
             return None
-        if self.on_device:
-            heads_h = self._heads_h[step & 3]
-            heads_h.copy_(self._parts2d, non_blocking=True)
-            ev = self._events[step & 3]
-            ev.record()
-        else:
-            heads_h, ev = self._parts2d.clone(), None
-        pending = _PendingParts(self, step, heads_h, ev)
+        pending = _PendingParts(self, step)
         return pending.result() if wait else pending
 
-    def _views(self, step, heads):
-        out = []
-        for r in range(self.world):
-            if int(heads[r][2]) != step or int(heads[r][3]) != r:
-                raise RuntimeError("header of rank %d for step %d carries step %d, rank %d" % (r, step, int(heads[r][2]), int(heads[r][3])))
+    def collect(self, step):
+        """Root: wait (bounded) until every rank's header of `step` is in the control page; the per-rank views."""
+        import time
+        self.flush()
+        deadline = time.monotonic() + self.acquire_timeout_s
+        out, r = [], 0
+        while r < self.world:
+            base = self._slot(r, step)
+            if int(self._ctl[base + 3]) < step:
+                if time.monotonic() > deadline:
+                    raise TimeoutError("root: no header of rank %d for step %d after %.0f s (its last: step %d)" % (r, step, self.acquire_timeout_s, int(self._ctl[base + 3])))
+                time.sleep(0)
+                continue
+            n, first, who, st = (int(self._ctl[base + k]) for k in range(4))
+            if st != step or who != r:
+                raise RuntimeError("header of rank %d for step %d carries step %d, rank %d" % (r, step, st, who))
             o = self._offset(r, step)
-            n = int(heads[r][0])
-            out.append((self._np[o:o + n * REC].view(self.dtype), int(heads[r][1])))
+            out.append((self._np[o:o + n * REC].view(self.dtype), first))
+            r += 1
         self.ranks_seen = len(out)
         return out
 

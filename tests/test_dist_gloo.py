@@ -77,6 +77,31 @@ for step in range(7):
         ng.release(step)
     else:
         assert parts is None
+# a header noted with an event is written only when the rank comes back, and only after the event has been waited for
+class Ev:
+    waited = False
+    def synchronize(self):
+        self.waited = True
+lazy = shard.NodeGather(16, tag='lazy', acquire_timeout_s=0.3)
+ev = Ev()
+lazy.acquire(0)
+lazy.host_records_view(0)[:2] = local[:2]
+h = lazy.gather(0, 2, first, wait=False, event=ev)
+assert not ev.waited and int(lazy._ctl[lazy._slot(rank, 0) + 3]) == -1
+if rank == 0:
+    try:
+        if world > 1:
+            h.result()  # rank 0's own header gets written by its flush, the others' have not been: bounded wait, then an error naming the rank
+            raise SystemExit('collect must not see headers that were never written')
+    except TimeoutError as e:
+        assert 'rank 1' in str(e)
+dist.barrier()
+lazy.flush()
+assert ev.waited and int(lazy._ctl[lazy._slot(rank, 0) + 3]) == 0
+dist.barrier()
+if rank == 0:
+    parts = h.result()
+    assert lazy.ranks_seen == world and all(len(p) == 2 for p, _ in parts)
 # flow control: without a release the writer of step + 2 must not get its segment
 slow = shard.NodeGather(8, tag='credit', acquire_timeout_s=0.3)
 for step in range(2):

@@ -371,6 +371,54 @@ def test_bench_sharded_file_step_two_ranks_rehearsal(native_libs, tmp_path):
     assert len(line["kernel_ms_by_rank"]["all"]) == 2
 
 
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()  # (does not initialise the GPU in this process)
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: the N > 1 step over RCCL, one process per GPU")
+def test_bench_sharded_file_step_two_gpus_over_rccl(native_libs, tmp_path):
+    """BASELINE configs[3] for real whenever the suite lands on a box with more than one GPU: `bench.py --gpus 2` started bare (it
+    launches its own two ranks, backend nccl = RCCL), rank r on GPU r scans its half of a 128 MiB recording, every GPU writes its packed
+    records into its own page-locked segment of node-shared memory (a PEER process's GPU writing memory rank 0's CPU reads: what a
+    world of one cannot show), the headers travel through the control page.  Delivered records and the resolved callback stream must
+    equal the oracle run over the whole recording, both record transports must agree."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = tmp_path / "stream2.npz"
+    out = _run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mib", "64", "--steps", "4", "--warmup", "1", "--dump-stream", str(dump)])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    nbuf = 2 * (64 << 20) // BB
+    assert line["n_gpus"] == 2 and line["config"]["buffers_total"] == nbuf and line["value"] > 0
+    assert "RCCL" in line["config"]["workload"] and line["config"]["record_transport"] == "node-shared page-locked host segments"
+    z = np.load(dump)
+    whole, _ = synth.fill_range(0, nbuf)
+    want = O.expected_records(whole, BB, dtype=A.RECORD_DTYPE)
+    assert z["records"].dtype == A.PACKED_DTYPE and np.array_equal(z["records"], A.pack_records(want, A.decode_records_host(want)))
+    ofr, oac = H.oracle_run(whole, BB)
+    ofr = ofr.copy()
+    ofr["msg"] = 0  # frames resolved from the packed form carry every field but the message bytes
+    H.assert_streams_equal(z["frames"], z["aircraft"], ofr, oac)
+    assert line["decoded_msgs_per_step"] == len(ofr) and line["ranks_seen"] == 2 and line["record_transports_agree"] is True
+    assert len(line["kernel_ms_by_rank"]["all"]) == 2
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: one UAT stream cut over two ranks, the loop's position over RCCL send / recv")
+def test_bench_uat_one_stream_cut_over_two_gpus(native_libs):
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = _run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "uat978", "--mib", "64", "--steps", "3", "--warmup", "1"])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    one = line["one_stream_cut_over_ranks"]
+    assert line["n_gpus"] == 2 and one["frames"] > 0 and one["equals_one_call"] is True, one
+
+
 NCCL_WORLD1 = r"""
 import os, sys
 sys.path.insert(0, %(root)r)
@@ -443,28 +491,29 @@ def test_root_gather_over_rccl_world_of_one(native_libs, tmp_path):
 
 
 def test_sharded_step_with_a_world_of_one_costs_what_the_plain_step_costs(native_libs):
-    """bench.py's N > 1 step (scan, hand-over of the packed records through node-shared page-locked memory with its credits, header
-    gather over RCCL) run with one rank against the plain single-GPU loop, both timed in the same process on the same input.  Measured:
-    2.4-4.4 % slower than the plain step (0.261-0.267 against 0.255 ms; the round-2 pair was 0.290-0.295 against 0.290, when both
-    moved 48 bytes a record).  What the plain loop does not have: one RCCL kernel per step beside the persistent scan (about two of the
-    points: measured with the gather replaced by a local copy) and a cross-stream wait in front of every scan.  The test holds the step
-    within 8 % (the two loops run seconds apart on a part whose clocks move: 0.948 has been seen) and checks that RCCL saw the rank."""
+    """bench.py's N > 1 step (scan, hand-over of the packed records through node-shared page-locked memory with its credits, the step's
+    header through the control page) run with one rank against the plain single-GPU loop, both timed in the same process on the same
+    input, the two loops alternating three times and the best window of each compared (the part's clocks move between windows; 0.948
+    was once seen for loops timed seconds apart).  Round 4 took the RCCL header gather out of the step (it put a collective's kernel
+    beside the persistent scan, about two of the four points the sharded step cost): the step must now be within 3 % of the plain one
+    (measured: profiles/r04_sharded_world_of_one.txt).  The functional checks -- the rank was seen, both record transports agree -- are
+    what gates; the ratio gets three processes to show itself."""
     import json
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     best = None
-    for attempt in range(2):  # one repeat: the two loops run seconds apart on a part whose clocks move
+    for attempt in range(3):
         out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port",
                     str(29541 + attempt), os.path.join(root, "bench.py"), "--gpus", "1", "--sharded-step-on-one-rank", "--steps", "200", "--warmup", "5"])
         assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
         line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         assert line["ranks_seen"] == 1 and line["record_transports_agree"] in (True, None)
-        ratio = line["value"] / line["independent_shards_value"]
+        ratio = line["sharded_over_plain"]
         best = ratio if best is None else max(best, ratio)
-        if best >= 0.92:
+        if best >= 0.97:
             break
-    assert best >= 0.92, "sharded step %.1f vs plain step %.1f Msamples/s" % (line["value"], line["independent_shards_value"])
+    assert best >= 0.97, "sharded step %.1f vs plain step %.1f Msamples/s" % (line["value"], line["independent_shards_value"])
 
 
 def test_device_field_decoder_equals_the_host_build(scanner):

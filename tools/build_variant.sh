@@ -7,5 +7,12 @@ if [ "$rev" = "WORK" ]; then cp -r $root/libadsb_amd/csrc $tmp/csrc; cp -r $root
 else mkdir -p $tmp/csrc $tmp/include; (cd $root && git archive $rev libadsb_amd/csrc include | tar -x -C $tmp); mv $tmp/libadsb_amd/csrc/* $tmp/csrc/; fi
 srcs="$tmp/csrc/scan1090.hip $tmp/csrc/capi.cpp $tmp/csrc/resolver1090.cpp"
 for f in scan2400.hip transport.cpp adsb1090_gpu_handler.cpp uat978.hip uat978_host.cpp uat978_gpu_handler.cpp; do [ -f $tmp/csrc/$f ] && srcs="$srcs $tmp/csrc/$f"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -shared -march=x86-64-v3 -ffp-contract=off -mllvm -amdgpu-atomic-optimizer-strategy=None $EXTRA_FLAGS -I$tmp/include -I$tmp/csrc -o $root/ab_libs/$name.so $srcs
+objs=""
+for f in $srcs; do
+  extra=""; case $(basename $f) in scan1090.hip|scan2400.hip) extra="-mllvm -amdgpu-atomic-optimizer-strategy=None";; esac
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -march=x86-64-v3 -ffp-contract=off $extra $EXTRA_FLAGS -I$tmp/include -I$tmp/csrc -c $f -o $tmp/$(basename $f).o &
+  objs="$objs $tmp/$(basename $f).o"
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/ab_libs/$name.so $objs
 rm -rf $tmp; echo built ab_libs/$name.so
