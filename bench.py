@@ -62,6 +62,9 @@ def parse_args(argv=None):
                     "2.4 MS/s -- BASELINE.json quotes that rate, nothing in the reference demodulates it (SURVEY.md F3/F5): parity unpinned, "
                     "the kernel is checked against its specification oracle/oracle2400.c")
     ap.add_argument("--time-every", type=int, default=4, help="HIP events around the scan kernel on every n-th launch of the timed region (1: all)")
+    ap.add_argument("--noise", type=int, default=None, help="N = 1: background noise amplitude of the synthetic input (default 3, the BASELINE workload; "
+                    "any other value is a sensitivity run, labelled as such: profiles/r04_sensitivity.txt)")
+    ap.add_argument("--spacing", type=int, default=None, help="N = 1: mean frame start-to-start spacing in samples (default 2000)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the end_to_end and uat978 blocks (profiling runs)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N > 1 ranks all on cuda:0 with the gloo backend: exercises the "
                     "multi-rank code path (sharding, record gather, resolve) on a one-GPU box; the numbers mean nothing")
@@ -265,7 +268,11 @@ def bench_1090_single(args, local_rank, A, synth, torch):
     BB = A.REF_BUFFER_BYTES
     nbuf = (args.mib << 20) // BB
     ncpu = max(1, len(os.sched_getaffinity(0)))
-    iq_host, injected = synth.fill_range(0, nbuf, nthreads=ncpu, rate_x10=args.rate)
+    over = {k: v for k, v in (("noise_amp", args.noise), ("mean_spacing", args.spacing)) if v is not None}
+    iq_host, injected = synth.fill_range(0, nbuf, nthreads=ncpu, rate_x10=args.rate, cfg=synth.default_cfg(**over) if over else None)
+    if over:
+        args.no_extras = True  # the other blocks are defined on the BASELINE workload
+        args.cpu_buffers = 0
     d_iq = torch.from_numpy(iq_host).cuda()
     torch.cuda.synchronize()
     sc = A.Scanner(local_rank, mode=args.rate)
@@ -318,7 +325,8 @@ def bench_1090_single(args, local_rank, A, synth, torch):
         "value": round(samples * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "setup_steps": SETUP_STEPS, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8 in / u16 integer (bit-exact)", "data": "synthetic",
-        "config": {"workload": ("BASELINE configs[1]+[2]: " + WORKLOAD_1090 % (args.mib, nbuf)) if args.rate == 20 else
+        "config": {"workload": ("SENSITIVITY RUN, not the BASELINE workload (%s): " % ", ".join("%s=%d" % kv for kv in over.items()) if over else "") +
+                               ("BASELINE configs[1]+[2]: " + WORKLOAD_1090 % (args.mib, nbuf)) if args.rate == 20 else
                                ("PARITY UNPINNED (no reference demodulates this rate, SURVEY.md F3/F5): %d MiB synthetic u8 IQ sampled at 2.4 MS/s (the "
                                 "generator's pulse trains integrated over 1/2.4 us bins, frames at random sub-sample offsets) through the library's "
                                 "2.4 MS/s mode: packed gate, five-phase preamble correlation, overlap-weighted Manchester slicing, CRC-24 + 1-bit "

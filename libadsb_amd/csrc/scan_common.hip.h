@@ -253,6 +253,16 @@ __device__ __forceinline__ void emit_raw(Emit& e, int lane, uint32_t offset, uin
         auto           sc = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
         const u32x4_s  lo = {sc(offset), sc(df | (nbits << 8) | (flags << 16) | ((uint32_t)(errorbit + 1) << 24)), sc(syn), sc(extra16)};
         const u32x4_s  hi = {sc((uint32_t)ba), sc((uint32_t)(ba >> 32)), sc((uint32_t)bb), sc((uint32_t)(bb >> 32))};
+#ifdef ADSB_AMD_EMIT_VECTOR // experiment (profiles/r04_sweep.txt): the record through lane 0's vector registers, no wait behind the stores
+        if (lane == 0)
+        {
+            uint4* const q = e.base + 2 * e.count;
+            q[0]           = make_uint4(lo.x, lo.y, lo.z, lo.w);
+            q[1]           = make_uint4(hi.x, hi.y, hi.z, hi.w);
+        }
+        e.count++;
+        return;
+#endif
         const uint64_t p  = reinterpret_cast<uint64_t>(e.base + 2 * e.count);
         // The wait is needed: a scalar store has NOT read its data registers when it issues (tools/isa_probe.hip overwrites them right
         // after the store and finds the new values in memory), and the compiler, which cannot see into the block, reuses them freely.
