@@ -378,6 +378,7 @@ def bench_1090_single(args, local_rank, A, synth, torch):
                              "frac": round((2.0 * samples + 32.0 * len(r24)) / (k24 / 50 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "traffic": measured_traffic("mode2400:%d" % nbytes), "algorithmic_bytes": int(2.0 * samples + 32.0 * len(r24))},
                 "records_per_step": int(len(r24)), "frames_injected": int(inj24), "accepted_frames": int(acc24),
+                "transmitted_frames_recovered": recovered_2400(A, synth, local_rank),
                 "note": "PARITY UNPINNED: 1 GiB of the generator's pulse trains sampled at 2.4 MS/s through ADSB_AMD_MODE_2400 (specification "
                         "oracle/oracle2400.c; no reference demodulator for this rate exists, SURVEY.md F3/F5); kernel by part and what is left to do: DESIGN.md section 11"}
             sc24.close()
@@ -389,6 +390,40 @@ def bench_1090_single(args, local_rank, A, synth, torch):
     sc.close()
     del d_iq
     torch.cuda.empty_cache()
+    return out
+
+
+def recovered_2400(A, synth, local_rank, nbuf=16):
+    """What the 2.4 MS/s mode brings back of what the generator transmits (the product on the GPU; no reference exists for this rate):
+    fraction of the transmitted frames -- those that start at least 300 samples before their buffer's end -- decoded with the right
+    bytes within one sample of where they start, at three settings.  The specification (oracle/oracle2400.c) is frozen; these three
+    numbers in the driver's record are what would show a loss of sensitivity."""
+    BB = A.REF_BUFFER_BYTES
+    out = {}
+    sc = A.Scanner(local_rank, mode=A.MODE_2400)
+    for name, over in (("noise_3", {}), ("noise_10", {"noise_amp": 10}), ("noise_12_signals_20_60", {"noise_amp": 12, "amp_lo": 20, "amp_hi": 60})):
+        cfg = synth.default_cfg(**over)
+        total = hit = 0
+        for b in range(nbuf):
+            iq, frames = synth.fill(b, BB, cfg, manifest=True, rate_x10=24)
+            got = {}
+            for r in sc.scan(iq, BB):
+                got.setdefault(bytes(r["msg"][:r["nbits"] // 8]), []).append(int(r["offset"]))
+            for f in frames:
+                if int(f["start"]) + 300 >= BB // 2:
+                    continue
+                msg = bytes(f["msg"][:int(f["nbits"]) // 8])
+                cand = [msg]
+                fb = int(f["flipped_bit"])
+                if fb >= 0:  # transmitted with one bit flipped: a DF11/17 comes back repaired
+                    m = bytearray(msg)
+                    m[fb >> 3] ^= 0x80 >> (fb & 7)
+                    cand.append(bytes(m))
+                total += 1
+                hit += any(c in got and any(abs(o - int(f["start"])) <= 1 for o in got[c]) for c in cand)
+        out[name] = round(hit / max(1, total), 4)
+        out[name + "_frames"] = total
+    sc.close()
     return out
 
 

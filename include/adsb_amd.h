@@ -352,7 +352,7 @@ int adsb_amd_uat_max_in_flight(void);
  * adsb_amd_uat_process_iq returns for the whole stream.  ADSB_AMD_ENOSPC: a chain of frames behind stale register bits left the window. */
 int adsb_amd_uat_part_scan(adsb_amd_uat_t* u, const void* iq_device, uint64_t nsamples);
 int adsb_amd_uat_part_finish(adsb_amd_uat_t* u, int64_t own_begin_sample, int64_t own_end_sample, int64_t entry_bit, int last, uint64_t offset,
-                             adsb_amd_uat_frame_fn cb, void* user, int64_t* exit_bit, int64_t* consumed); /* how many submitted calls a handle holds before submit returns ADSB_AMD_ESTATE */
+                             adsb_amd_uat_frame_fn cb, void* user, int64_t* exit_bit, int64_t* consumed);
 int adsb_amd_uat_collect(adsb_amd_uat_t* u, adsb_amd_uat_frame_fn cb, void* user, int64_t* consumed);
 /* Parity helpers for the CPU tests: the scan loop's filter for the 17 steps after a jump (bit t set = step t can still fire, given a
  * register's 18 old bits and the bits that enter it, both in stream order), and the 18-bit check words in the same order. */

@@ -224,12 +224,22 @@ int make_args(adsb_amd_ctx* c, const void* iq_device, size_t nbytes, size_t buff
     uint64_t total    = (uint64_t)a->chunks_per_buf * nbuf;
     if (total > 0x7FFFFFFFull) return fail(c, ADSB_AMD_EINVAL, "input too large for one scan call");
     a->total_chunks = (uint32_t)total;
+    a->main_chunks  = a->total_chunks;
     // groups of 16 neighbouring chunks per XCD once every work counter gets several of them; chunk by chunk for small inputs (a live
     // 262144-byte buffer is 32 chunks: they must spread over 32 waves, not queue up behind two)
     a->group_log2 = total >= 16ull * 8 * c->nxcd * kSubRanges ? 4u : 0u;
     a->crc_tab      = c->crc_tab;
     a->nxcd         = c->nxcd;
     a->ncu          = c->ncu;
+    // The last eighth of a large input is not pre-assigned to an XCD (take_next, scan_common.hip.h): whole rounds of groups over all counters stay in
+    // the main part, so every counter's share is the same number of whole groups.  A pool only where every wave is sure to reach it: the main part
+    // gives every wave at least four work items (its two fixed ones, then tickets).
+    if (a->group_log2)
+    {
+        const uint32_t round = (c->nxcd * kSubRanges) << a->group_log2;
+        const uint32_t main  = (a->total_chunks - a->total_chunks / 8u) / round * round;
+        if ((uint64_t)main >= 4ull * scan_grid(*a)) a->main_chunks = main;
+    }
     return ADSB_AMD_OK;
 }
 

@@ -503,6 +503,7 @@ struct WorkRange
     uint32_t range;      // which counter
     uint32_t xcd, sub, nxcd;
     uint32_t glog;       // log2 of the group size (ScanArgs::group_log2)
+    uint32_t counter;    // index of the counter the wave draws from: its own (range), later a pool counter (kPoolBase + ..)
 #ifdef ADSB_AMD_DIAG_NO_GRAB
     uint32_t diag_k = 0;
 #endif
@@ -521,14 +522,15 @@ __device__ __forceinline__ void range_share(const ScanArgs& a, WorkRange& w, uin
     w.xcd               = xcd;
     w.sub               = sub;
     w.range             = xcd * kSubRanges + sub;
+    w.counter           = w.range;
     w.first             = 0;
     w.glog              = a.group_log2;
     const uint32_t gsz  = 1u << w.glog;
-    const uint32_t tg   = (a.total_chunks + gsz - 1) >> w.glog;
+    const uint32_t tg   = (a.main_chunks + gsz - 1) >> w.glog;
     const uint32_t cx   = tg / nxcd + (xcd < tg % nxcd ? 1u : 0u);                 // groups of this XCD
     const uint32_t ng   = cx > sub ? (cx - sub + kSubRanges - 1) / kSubRanges : 0u; // of this counter
     uint32_t       nv   = ng << w.glog;
-    const uint32_t tail = a.total_chunks - ((tg - 1) << w.glog);                   // chunks of the last group (tg >= 1: the launch has work)
+    const uint32_t tail = a.main_chunks - ((tg - 1) << w.glog);                    // chunks of the last group (tg >= 1: the launch has work)
     if (ng && tail < gsz && (tg - 1) % nxcd == xcd && ((tg - 1) / nxcd) % kSubRanges == sub) nv -= gsz - tail;
     w.end = nv;
 }
@@ -557,7 +559,7 @@ __device__ __forceinline__ uint32_t grab_issue(const ScanArgs& a, const WorkRang
 #ifdef ADSB_AMD_DIAG_NO_GRAB // diagnostic builds: a ticket without memory traffic (every wave counts for itself: fixed stride inside its counter's share)
     v = w.slot + w.nslot * const_cast<WorkRange&>(w).diag_k++;
 #else
-    if (lane == 0) v = atomicAdd(&a.work_counters[w.range * kCounterStride], 1u);
+    if (lane == 0) v = atomicAdd(&a.work_counters[w.counter * kCounterStride], 1u);
 #endif
     return v;
 }
@@ -583,14 +585,32 @@ constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
 // Small inputs (group_log2 == 0: a live buffer) do not steal: a handful of chunks, and the probes would cost more than they balance.
 __device__ __forceinline__ uint32_t take_next(const ScanArgs& a, WorkRange& w, uint32_t ticket, int lane)
 {
+    // The pool (round 4).  The XCDs get equal shares of the recording but do not run equally fast: the last wave of the fastest XCD left 205 us
+    // into a launch, that of the slowest 228 us, and which one is slow changes from launch to launch (profiles/r04_sweep.txt).  So the last
+    // eighth of a large input belongs to nobody: a wave whose own counter is dry draws from pool counter p = its slot modulo the number of
+    // counters -- every pool counter is served by waves of every XCD, those that are done early take more -- chunk main + p + ticket * counters.
+    // One returning atomic is waited for at the switch, once per wave; what is lost is the L2 hit on a pool chunk's halo.
+    // (The host makes a pool only when every wave is sure to come here: shares of at least four items per wave, make_args in capi.cpp.  As many pool
+    // counters as there are own counters, or as a counter has waves if that is fewer: every pool counter has waves that serve it.)
+    const uint32_t nranges = w.nxcd * kSubRanges, npool = nranges < w.nslot ? nranges : w.nslot;
+    if (w.counter >= kPoolBase)
+    {
+        const uint32_t c = a.main_chunks + (w.counter - kPoolBase) + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket) * npool;
+        return c < a.total_chunks ? c : kNoChunk;
+    }
     const uint32_t v = grab_value(w, ticket);
     if (v < w.end) return w.chunk_of(v);
+    if (a.main_chunks < a.total_chunks)
+    {
+        w.counter        = kPoolBase + w.slot % npool;
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)grab_issue(a, w, lane));
+        const uint32_t c = a.main_chunks + (w.counter - kPoolBase) + t * npool;
+        return c < a.total_chunks ? c : kNoChunk;
+    }
 #if !defined(ADSB_AMD_STEAL) || !ADSB_AMD_STEAL
-    (void)a, (void)lane;
     return kNoChunk; // measured and not kept (profiles/r04_sweep.txt): with the stealing below the kernel took 0.24-0.28 ms instead of 0.211
 #else
     if (a.group_log2 == 0) return kNoChunk;
-    const uint32_t nranges = a.nxcd * kSubRanges;
     for (uint32_t tries = 0; tries < 4u; tries++)
     {
         uint32_t key = 0;

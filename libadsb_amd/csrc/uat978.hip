@@ -1283,7 +1283,13 @@ __global__ __launch_bounds__(256) void uat_order_within_kernel(const uint32_t* _
 // forward, so the list is cut into blocks of kUatDecideNodes: uat_succ_kernel resolves every node to the first node its path reaches
 // outside its block (pointer jumping in LDS, 12 rounds), uat_mark_kernel walks those exits from the first node to its own block (at
 // most one dependent load per block) and marks the path inside the block by doubling.
-constexpr int kUatDecideThreads = 1024, kUatDecideLevels = 12, kUatNodesPerLane = (int)kUatDecideNodes / kUatDecideThreads;
+// Threads of a decision workgroup (4096 nodes each).  256 since round 4: with calls in flight the 1024-thread form waited for sixteen free wave
+// slots on one CU beside a demodulation kernel that fills every SIMD (13 -> 98 us resident); four waves find room.  Pipelined step 0.540-0.545 ->
+// 0.523-0.527 ms, calls back to back 0.750-0.754 -> 0.788-0.794 (the kernels themselves are slower with a quarter of the lanes).
+#ifndef ADSB_AMD_UAT_DECIDE_THREADS
+#define ADSB_AMD_UAT_DECIDE_THREADS 256
+#endif
+constexpr int kUatDecideThreads = ADSB_AMD_UAT_DECIDE_THREADS, kUatDecideLevels = 12, kUatNodesPerLane = (int)kUatDecideNodes / kUatDecideThreads;
 static_assert((1u << kUatDecideLevels) == kUatDecideNodes, "2^levels successors cover a block");
 constexpr uint32_t kIndexMask = 0x7FFFFFFFu;
 

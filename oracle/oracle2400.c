@@ -3,6 +3,12 @@
  *
  * TEST INFRASTRUCTURE ONLY (part of liboracle1090.so; see oracle1090.h).
  *
+ * SPECIFICATION v3, FROZEN (round 4).  Rounds 2-3 changed two rules of this file on measured data (the 3 : 2 gate, the 8 P >= T
+ * qualifying line) and bought kernel time with them; that is not kernel efficiency and is not repeated: from here on the kernel gets
+ * faster against THIS text or not at all.  What the rules recover is in the driver's record: bench.py's mode_2400 block carries the
+ * fraction of transmitted frames the mode brings back at noise +-3, +-10 and +-12 with 20-60 LSB signals (99.1 / 88.2 / 57.6 % when
+ * the rules were frozen), so a later loss of sensitivity shows.
+ *
  * PARITY UNPINNED, and not a restatement of anything in the reference tree: libadsb demodulates 2 samples per microsecond only
  * (ADSB1090.cpp:148, 757-758); the only 2.4 MS/s demodulator in its ecosystem is flightaware dump1090's demod_2400.c, which the
  * reference globs into a CMake variable and never compiles or links, and whose submodule directory is empty in the snapshot
