@@ -231,13 +231,16 @@ int make_args(adsb_amd_ctx* c, const void* iq_device, size_t nbytes, size_t buff
     a->crc_tab      = c->crc_tab;
     a->nxcd         = c->nxcd;
     a->ncu          = c->ncu;
-    // The last eighth of a large input is not pre-assigned to an XCD (take_next, scan_common.hip.h): whole rounds of groups over all counters stay in
+    // The last sixteenth of a large input (a quarter: 0.2195 ms, an eighth: 0.2131, a sixteenth: 0.2116) is not pre-assigned to an XCD (take_next, scan_common.hip.h): whole rounds of groups over all counters stay in
     // the main part, so every counter's share is the same number of whole groups.  A pool only where every wave is sure to reach it: the main part
     // gives every wave at least four work items (its two fixed ones, then tickets).
     if (a->group_log2)
     {
         const uint32_t round = (c->nxcd * kSubRanges) << a->group_log2;
-        const uint32_t main  = (a->total_chunks - a->total_chunks / 8u) / round * round;
+#ifndef ADSB_AMD_POOL_DIV
+#define ADSB_AMD_POOL_DIV 16u
+#endif
+        const uint32_t main  = (a->total_chunks - a->total_chunks / ADSB_AMD_POOL_DIV) / round * round;
         if ((uint64_t)main >= 4ull * scan_grid(*a)) a->main_chunks = main;
     }
     return ADSB_AMD_OK;

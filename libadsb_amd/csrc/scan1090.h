@@ -49,7 +49,7 @@ struct ScanArgs
     uint32_t           cpb_magic;    // floor(2^32 / chunks_per_buf) (0xFFFFFFFF for one chunk per buffer): chunk -> (buffer, chunk in buffer) without a division
     uint32_t           total_chunks;
     uint32_t           main_chunks;  // chunks [0, main_chunks) are dealt out by the XCDs' own counters (scan_common.hip.h, WorkRange), the rest -- the pool,
-                                     // about an eighth, none for small inputs -- by counters that waves of every XCD draw from once their own is dry
+                                     // about a sixteenth, none for small inputs -- by counters that waves of every XCD draw from once their own is dry
     const uint32_t*    crc_tab;      // 112 entries (ModesChecksumTable semantics)
     adsb_amd_record_t* chunk_records; // total_chunks * cap raw records: one region of `cap` per chunk, or (log_cap != 0) one log of log_cap per wave
     uint32_t*          chunk_dir;     // two words per chunk: index of its first raw record in chunk_records (log mode), records kept (<= room)

@@ -587,7 +587,7 @@ __device__ __forceinline__ uint32_t take_next(const ScanArgs& a, WorkRange& w, u
 {
     // The pool (round 4).  The XCDs get equal shares of the recording but do not run equally fast: the last wave of the fastest XCD left 205 us
     // into a launch, that of the slowest 228 us, and which one is slow changes from launch to launch (profiles/r04_sweep.txt).  So the last
-    // eighth of a large input belongs to nobody: a wave whose own counter is dry draws from pool counter p = its slot modulo the number of
+    // sixteenth of a large input belongs to nobody: a wave whose own counter is dry draws from pool counter p = its slot modulo the number of
     // counters -- every pool counter is served by waves of every XCD, those that are done early take more -- chunk main + p + ticket * counters.
     // One returning atomic is waited for at the switch, once per wave; what is lost is the L2 hit on a pool chunk's halo.
     // (The host makes a pool only when every wave is sure to come here: shares of at least four items per wave, make_args in capi.cpp.  As many pool
