@@ -512,7 +512,11 @@ void Resolver1090::helper_main()
         uint64_t produced = produced_.load(std::memory_order_relaxed);
         do
         {
-            while (produced - consumed_.load(std::memory_order_acquire) >= kRing) _mm_pause();
+            for (unsigned spins = 0; produced - consumed_.load(std::memory_order_acquire) >= kRing; spins++)
+            {
+                if (spins < 4096) _mm_pause();
+                else std::this_thread::yield(); // the consumer is not running (fewer CPUs than threads right now): let it
+            }
             Block& blk = blocks_[produced % kRing];
             gate_dispatch(blk, w, job);
             produced_.store(++produced, std::memory_order_release);
@@ -555,7 +559,14 @@ long Resolver1090::run(const Job& job, size_t nbuffers, adsb_amd_on_changed_fn c
 {
     const size_t n         = job.n;
     long         accepted  = 0;
-    static const unsigned cores   = std::thread::hardware_concurrency();
+    // CPUs this process may run on (its affinity mask: a cgroup, taskset or a NUMA binding can leave one where the machine has many): with a
+    // single allowed CPU the caller and the helper would spin against each other a time slice at a time, so everything stays on the caller's thread
+    static const unsigned cores = []() -> unsigned {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) return (unsigned)CPU_COUNT(&set);
+        return std::thread::hardware_concurrency();
+    }();
     static const int      threads = std::getenv("ADSB_AMD_RESOLVER_THREADS") ? std::atoi(std::getenv("ADSB_AMD_RESOLVER_THREADS")) : 2;
     if (n >= kParallelMin && cores > 1 && threads > 1)
     {
@@ -576,10 +587,11 @@ long Resolver1090::run(const Job& job, size_t nbuffers, adsb_amd_on_changed_fn c
         for (;;)
         {
             uint64_t produced;
-            while ((produced = produced_.load(std::memory_order_acquire)) == consumed)
+            for (unsigned spins = 0; (produced = produced_.load(std::memory_order_acquire)) == consumed; spins++)
             {
                 if (gate_done_.load(std::memory_order_acquire) && produced_.load(std::memory_order_acquire) == consumed) goto drained;
-                _mm_pause();
+                if (spins < 4096) _mm_pause();
+                else std::this_thread::yield(); // the helper is not running: let it
             }
             Block& blk = blocks_[consumed % kRing];
             update_pass(blk, job, cb, user);
