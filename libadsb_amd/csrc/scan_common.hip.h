@@ -408,8 +408,26 @@ __device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWin
             r.cont_hi        = make_uint2(hi.x, hi.y);
         }
     }
+    else if (g.g0 + (uint32_t)kChunk <= g.n)
+    { // The buffer's last chunk when the buffer is a whole number of rows (every reference buffer is: 131072 samples): all eight rows lie inside,
+      // only the halo crosses the end.  Eight plain loads back to back and a guarded halo -- the general path below waits for every row
+      // before it looks at the next (a call may follow each), eight memory round trips in a row for one chunk in 32: those chunks were
+      // the stragglers at the end of a launch.
+        const uint8_t* const base = g.buf + 2ull * g.g0 + 16u * (uint32_t)lane;
+#pragma unroll
+        for (int k = 0; k < kRows; k++) r.row[k] = *reinterpret_cast<const uint4*>(base + (uint32_t)(k * kRowSamples * 2));
+        const uint32_t gh = g.g0 + (uint32_t)kChunk; // first sample of the halo
+        if (SPLIT) r.cont_hi = load_iq8_guarded(g.buf, gh + 4u * (uint32_t)lane, g.n);
+        else
+        {
+            const uint32_t gk = gh + 8u * (uint32_t)lane;
+            if (gk + 8u <= g.n) r.row[kRows] = *reinterpret_cast<const uint4*>(g.buf + 2ull * gk);
+            else if (gk < g.n) r.row[kRows] = load_iq16_tail(g.buf, gk, g.n);
+            else r.row[kRows] = make_uint4(0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
+        }
+    }
     else
-    { // last chunk of a buffer: lanes whose 16 bytes lie inside still use the vector load, the rest the guarded path
+    { // a chunk that the buffer's end cuts through: lanes whose 16 bytes lie inside still use the vector load, the rest the guarded path
         const uint32_t gl = g.g0 + 8u * (uint32_t)lane;
 #pragma unroll
         for (int k = 0; k < kRows + (SPLIT ? 0 : 1); k++)
