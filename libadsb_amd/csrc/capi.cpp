@@ -168,6 +168,12 @@ int ensure_slot(adsb_amd_ctx* c, Slot& s, size_t chunks, size_t cap, unsigned ma
     }
     free_slot(s);
     size_t nch = chunks ? chunks : 1;
+    if (const char* e = std::getenv("ADSB_AMD_DIAG_ALLOC_PAD_KB"))
+    { // measurements only: shift where the slot's buffers lie (profiles/r04_sweep.txt, item 0) -- the pad is never freed
+        void* pad = nullptr;
+        const size_t kb = (size_t)std::atol(e);
+        if (kb) (void)hipMalloc(&pad, kb << 10);
+    }
     HIP_TRY(c, hipMalloc(&s.counts, 2 * nch * sizeof(uint32_t)));
     s.sums_words = ((nch + kOrderChunks - 1) / kOrderChunks) * kSumStride;
     s.sums_phase = 0;

@@ -26,15 +26,15 @@ for path in sys.argv[1:]:
     scanners.append((path, sc))
 for rnd in range(2):
     for path, sc in scanners:
-        t0 = time.perf_counter(); ks = []; ts = []; tf = []; tsub = []
+        t0 = time.perf_counter(); ks = []; ts = []; tf = []; tsub = []; by_slot = ([], [])
         sc.submit(d.data_ptr(), d.numel(), BB, st, 0); i = 1
         while time.perf_counter() - t0 < secs:
             ta = time.perf_counter()
             sc.submit(d.data_ptr(), d.numel(), BB, st, i & 1)
             tb = time.perf_counter()
             fetch(sc, (i - 1) & 1); tc = time.perf_counter(); tsub.append(tb - ta); tf.append(tc - tb); tm = timing(sc, (i - 1) & 1); i += 1
-            if tm: ks.append(tm[0]); ts.append(tm[1])
+            if tm: ks.append(tm[0]); ts.append(tm[1]); by_slot[i & 1].append(tm[0])
         fetch(sc, (i - 1) & 1)
         el = time.perf_counter() - t0
-        print("%-22s round %d: kernel ms median (second half) %.4f  scan start -> count on the host %.4f  step %.4f ms" % (os.path.basename(path), rnd, statistics.median(ks[len(ks) // 2:]), statistics.median(ts[len(ts) // 2:]), el / i * 1e3) + "  (host: submit %.1f us, fetch %.1f us)" % (statistics.median(tsub) * 1e6, statistics.median(tf) * 1e6), flush=True)
+        print("%-22s round %d: kernel ms median (second half) %.4f  scan start -> count on the host %.4f  step %.4f ms" % (os.path.basename(path), rnd, statistics.median(ks[len(ks) // 2:]), statistics.median(ts[len(ts) // 2:]), el / i * 1e3) + "  slots %.4f %.4f" % tuple(statistics.median(b[len(b) // 2:]) if b else 0 for b in by_slot) + "  (host: submit %.1f us, fetch %.1f us)" % (statistics.median(tsub) * 1e6, statistics.median(tf) * 1e6), flush=True)
         time.sleep(0.3)
