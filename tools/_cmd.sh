@@ -1,1 +1,3 @@
-for kb in 0 64 1024 4096 16384 65536 1000 3000 100000; do echo "pad $kb KB"; ADSB_AMD_DIAG_ALLOC_PAD_KB=$kb AB_SECONDS=1.0 python3 tools/sustained_ab.py ab_libs/pad.so ab_libs/pad.so 2>&1 | grep -v amdgpu.ids | grep "round 1" | cut -c1-40,60-75,125-150; done
+python3 -m pytest tests -x -q -m gpu > gpurun_out/r04_t24.log 2>&1; tail -2 gpurun_out/r04_t24.log
+python3 tools/soak.py 40 > gpurun_out/r04_soak.txt 2>&1; tail -4 gpurun_out/r04_soak.txt
+python3 __graft_entry__.py --smoke 2>&1 | tail -3
