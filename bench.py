@@ -15,8 +15,8 @@ N > 1 (BASELINE configs[3], the recorded-file case): the recording is N GiB (wea
 buffers [r*B/N, (r+1)*B/N) (no halo: buffers are independent; a trailing partial buffer is never
 delivered, reference RTLSDR.hpp:419-442).  One step = every rank scans its shard and its packed records land in rank 0's
 host memory, in recording order: each GPU writes its own segment of node-shared page-locked memory over its own PCIe link,
-only a 32-byte header per rank is gathered over RCCL (shard.NodeGather; --rccl-gather or a node without /dev/shm room: the
-records themselves are gathered over RCCL).  Steps are pipelined the same way.  `value` is the GPU side; a second timed loop
+and a 32-byte header per rank goes through the shared control page (shard.NodeGather: no collective per step; --rccl-gather
+or a node without /dev/shm room: the records themselves are gathered over RCCL).  Steps are pipelined the same way.  `value` is the GPU side; a second timed loop
 with the sequential resolver inside gives end_to_end_msamples_per_s.
 
 --workload uat978: BASELINE configs[4]; with N > 1 replicas (`value`) and one N GiB stream cut over the ranks.
@@ -579,7 +579,7 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
 
     def deliver_node(slot):
         """Records of `slot` -> this rank's segment of the node-shared page-locked memory (device to host over the rank's own link, on
-        the side stream), then the header gather; rank 0 gets one view per rank, in recording order.  The segment is the one of step - 2:
+        the side stream), the step's header through the shared control page once the copy's event is done; rank 0 gets one view per rank, in recording order.  The segment is the one of step - 2:
         acquire() waits until rank 0 has released that step."""
         step = step_no[0]
         step_no[0] += 1
@@ -744,12 +744,12 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
                                    + "; rank r scans buffers [r*B/N, (r+1)*B/N), sorted records of all ranks delivered to rank 0's host in "
                                      "recording order: %s (%s)"
                                    % ("every GPU writes its records over its own PCIe link into a page-locked segment of node-shared host memory, "
-                                      "one gather of 32-byte headers per step" if ng is not None else
+                                      "a 32-byte header per rank and step through the shared control page (no collective per step)" if ng is not None else
                                       "one fixed-size gather of the records per step, device to device, then rank 0's GPU -> its host",
                                       "RCCL over xGMI" if on_device else "gloo: REHEARSAL on one GPU, numbers meaningless"),
                        "bytes_per_gpu": nbytes, "buffers_per_gpu": nbuf, "buffers_total": nbuf_total,
                        "sharding": "contiguous buffer ranges, no halo, no collective on the sample path; per step one %s" %
-                                   ("header gather (records go host-side through node-shared memory)" if ng is not None else "record gather"),
+                                   ("header per rank in node-shared memory, written by the rank's host thread (records go host-side through node-shared memory too)" if ng is not None else "record gather"),
                        "record_transport": "node-shared page-locked host segments" if ng is not None else "RCCL record gather", "pipelined": True},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic(nbytes), "kernel": "scan1090_kernel", "kernel_ms": round(kernel_ms, 4),
