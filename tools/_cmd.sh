@@ -1,2 +1,4 @@
-python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/r04_t25.log 2>&1; tail -2 gpurun_out/r04_t25.log
-AB_CONTEXTS=3 python3 tools/ab_dense.py ab_libs/tailfast.so ab_libs/pf.so ab_libs/fulla.so ab_libs/pfa.so 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_ab34.txt
+tools/prof.sh r04_final > gpurun_out/r04_prof_final.log 2>&1
+tools/prof.sh r04_mode2400 --rate 24 > gpurun_out/r04_prof_2400.log 2>&1
+python3 tools/stamps.py ab_libs/stamps.so 4 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_stamps_final.txt
+python3 tools/stamps_waves.py ab_libs/stamps.so 2>&1 | grep -v amdgpu.ids | head -33 | tee gpurun_out/r04_waves_final.txt
