@@ -511,7 +511,8 @@ __device__ __forceinline__ void publish(const ScanArgs& a, const Pending& p, int
 //   * no more than 128 waves share a counter (each on its own 128-byte line: 131 072 atomics on eight counters that shared one line took
 //     1.1 ms; on 32 lines they cost nothing measurable).
 // A wave's work items are numbered v = 0, 1, .. inside its counter's share ("virtual" indices): the first two are fixed (slot, slot +
-// nslot), every later one comes from the counter, read two chunks ahead so that its latency never shows (chunks differ in cost -- candidates
+// nslot), every later one comes from the counter -- the ticket drawn in front of a trip's prefetch, its value read at the end of the trip: half a
+// chunk's time for the atomic (take_next) -- (chunks differ in cost -- candidates
 // to demodulate --, and with a fixed stride the slowest of 4096 waves sets the kernel time).  chunk_of(v) is the chunk.
 struct WorkRange
 {
