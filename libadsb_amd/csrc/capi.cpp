@@ -596,7 +596,11 @@ int fetch_slot(adsb_amd_ctx* c, Slot& s, unsigned what)
     static const bool diag_no_copy = std::getenv("ADSB_AMD_DIAG_NO_COPY") != nullptr; // measurements only: the scan without the record copy beside it
     if (s.nrecords && !diag_no_copy)
     {
-        if (c->count_path == kCountHost) HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, s.ev_order, 0)); // the count comes from the pass's last workgroup, others may still be moving records
+        // The count comes from the pass's last workgroup: others may still be moving records.  The pass's event rides on its dispatch, and a
+        // stream that is told to wait for such an event right away can find the event still standing for its previous use (seen with the
+        // scan's stop event: a pass on another stream started before its scan had ended); the HOST, which has seen this launch's stamp, cannot:
+        // it waits for the event here (microseconds), then the copy needs no wait of its own.
+        if (c->count_path == kCountHost) HIP_TRY(c, hipEventSynchronize(s.ev_order));
         if (what & ADSB_AMD_OUT_RECORDS)
             HIP_TRY(c, hipMemcpyAsync(s.host, s.dense, s.nrecords * sizeof(adsb_amd_record_t), hipMemcpyDeviceToHost, c->copy_stream));
         if (what & ADSB_AMD_OUT_DECODED)
@@ -715,7 +719,7 @@ int fetch_device_impl(adsb_amd_ctx_t* c, int slot, void* dst_device, size_t cap,
         if (s.nrecords)
         {
             hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->copy_stream;
-            if (c->count_path == kCountHost) HIP_TRY(c, hipStreamWaitEvent(st, s.ev_order, 0));
+            if (c->count_path == kCountHost) HIP_TRY(c, hipEventSynchronize(s.ev_order)); // (see fetch_slot)
             // hipMemcpyDefault: the destination may be device memory or page-locked / registered host memory (shard.NodeGather)
             static_assert(sizeof(adsb_amd_record_t) == sizeof(adsb_amd_packed_t), "one size for both forms");
             HIP_TRY(c, hipMemcpyAsync(dst_device, packed ? static_cast<const void*>(s.packed) : static_cast<const void*>(s.dense),

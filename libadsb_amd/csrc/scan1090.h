@@ -100,7 +100,7 @@ inline uint32_t scan_grid(const ScanArgs& a)
 }
 
 // Demodulation kernel (fills the raw record regions / logs and the chunk directory; zeroes `total_and_overflow`).
-// `start` / `stop` (both or neither): events that take the kernel's own start and end times -- they ride on the dispatch
+// `start` / `stop` (either may be NULL): events that take the kernel's own start and end times -- they ride on the dispatch
 // (hipExtLaunchKernelGGL), where two hipEventRecord calls around the launch are packets of their own on the stream, 3-5 us each.
 hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // Ordering pass: the sorted gather into `dense` (+ field decode).  `total_and_overflow` is a device uint32_t[2]: {number of

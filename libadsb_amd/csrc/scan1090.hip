@@ -1009,7 +1009,7 @@ hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipS
     if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
     // persistent single-wave workgroups: enough to fill every CU at the LDS-limited occupancy (16 per CU)
     const uint32_t grid = scan_grid(a);
-    if (start && stop) hipExtLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, start, stop, 0, a, total_and_overflow);
+    if (start || stop) hipExtLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, start, stop, 0, a, total_and_overflow); // (either may be NULL)
     else hipLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
     return hipGetLastError();
 }

@@ -493,7 +493,7 @@ hipError_t launch_scan2400(const ScanArgs& a, uint32_t* total_and_overflow, hipS
     if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
     // persistent single-wave workgroups, as many as the LDS lets a CU hold (16 x 10 208 bytes), in whole (XCD, sub-range) units
     const uint32_t grid = scan_grid(a);
-    if (start && stop) hipExtLaunchKernelGGL(scan2400_kernel, dim3(grid), dim3(64), 0, stream, start, stop, 0, a, total_and_overflow);
+    if (start || stop) hipExtLaunchKernelGGL(scan2400_kernel, dim3(grid), dim3(64), 0, stream, start, stop, 0, a, total_and_overflow); // (either may be NULL)
     else hipLaunchKernelGGL(scan2400_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
     return hipGetLastError();
 }

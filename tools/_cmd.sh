@@ -1,4 +1,4 @@
-tools/prof.sh r04_final > gpurun_out/r04_prof_final.log 2>&1
-tools/prof.sh r04_mode2400 --rate 24 > gpurun_out/r04_prof_2400.log 2>&1
-python3 tools/stamps.py ab_libs/stamps.so 4 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_stamps_final.txt
-python3 tools/stamps_waves.py ab_libs/stamps.so 2>&1 | grep -v amdgpu.ids | head -33 | tee gpurun_out/r04_waves_final.txt
+python3 -m pytest tests -x -q -m gpu > gpurun_out/r04_t29.log 2>&1; tail -2 gpurun_out/r04_t29.log
+python3 bench.py --steps 20 --warmup 5 --no-extras --cpu-buffers 0 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
