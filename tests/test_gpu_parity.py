@@ -159,6 +159,26 @@ def test_async_two_slot_pipeline(scanner):
     assert 0 < k_ms <= t_ms
 
 
+def test_timing_events_on_every_nth_scan(native_libs):
+    """adsb_amd_set_timing: the two events that time the demodulation kernel ride on every n-th submit; a scan without them reports no time."""
+    sc = A.Scanner()
+    iq, _ = synth.fill_range(3, 4)
+    want = sc.scan(iq, BB)
+    assert sc.timing_if_timed(0) is not None  # the default: every scan
+    sc.set_timing(2)
+    seen = []
+    for _ in range(4):
+        H.assert_records_equal(sc.scan(iq, BB), want)
+        seen.append(sc.timing_if_timed(0))
+    assert [t is not None for t in seen] == [True, False, True, False] and all(0 < t[0] <= t[1] for t in seen if t)
+    with pytest.raises(A.AdsbAmdError, match="timed"):
+        sc.timing(0)
+    sc.set_timing(0)
+    sc.scan(iq, BB)
+    assert sc.timing_if_timed(0) is None
+    sc.close()
+
+
 def test_cxx_drop_in_handler_matches_reference_test_flow(native_libs, tmp_path):
     # the reference's own test shape (tests/test_1090.cpp): C++ listener, ADSB::test::TryCreateADSB1090Handler, HandleData,
     # one formatted line per OnChanged; here against the oracle's callback text instead of the (input-less) goldens
