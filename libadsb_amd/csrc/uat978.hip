@@ -462,35 +462,63 @@ constexpr int kUatTile      = 1024; // samples staged (128 chunks of 8)
 constexpr int kUatTileValid = 1023; // the last entry would need the first phase of the next tile
 constexpr int kUatTileStride = 896; // uplink frames: tile t starts 896 t samples after the first (7 groups of 64 bits)
 
+// Out of line (two call sites), so the address spaces of its operands are spelled out: as generic pointers the stream and the table were
+// read by flat loads, which count against the LDS counter as well and are waited for with everything else.
+//   counter  null, or the work counter to draw the wave's next ticket from.  The returning atomic is issued BEHIND the tile's table
+//            look-ups and waited for together with them, so that its round trip to the memory side (device scope: past the L2) is not
+//            a wait of its own at the head of every match.  Returns the ticket (uniform), 0xFFFFFFFF without a counter.
+typedef __attribute__((address_space(1))) const uint16_t* g_cu16;
+typedef __attribute__((address_space(1))) uint32_t*       g_u32;
+typedef __attribute__((address_space(3))) int16_t*        lds_i16;
+
+__device__ __forceinline__ uint32_t draw_ticket(g_u32 counter, int lane)
+{ // one statement = issue + wait: the compiler does not track the counter of an asm's load, so the result must be there when the asm ends
+    uint32_t t = 0;
+    if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(counter), "v"(1u) : "memory");
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+}
+
 template <bool PHASES_GIVEN>
-__device__ __noinline__ void stage_dphi(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n, uint64_t base,
-                                           int16_t* dphi_s, int lane)
+__device__ __noinline__ uint32_t stage_dphi(g_cu16 in, g_cu16 lut, uint64_t n, uint64_t base, lds_i16 dphi_s, int lane, g_u32 counter)
 {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); // (HIP's uint4 is a class: no assignment across address spaces)
+    typedef __attribute__((address_space(1))) const u32x4* g_cu4;
+    typedef __attribute__((address_space(3))) u32x4*       lds_u4;
+    uint32_t   ticket  = 0xFFFFFFFFu;
+    // the arguments of a function arrive in vector registers; the stream, the table and the counter are the same for every lane: as scalar
+    // bases the sixteen look-ups need a 32-bit offset register each instead of a 64-bit address (what the caller may keep live across
+    // the call is what this function leaves untouched)
+    auto uniform64 = [](uint64_t v) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v); };
+    in = (g_cu16)uniform64((uint64_t)in), lut = (g_cu16)uniform64((uint64_t)lut), counter = (g_u32)uniform64((uint64_t)counter);
+    base = uniform64(base), n = uniform64(n);
     const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
     if (aligned && base + (uint64_t)kUatTile + 1 <= n)
     { // the whole tile and the sample after it lie inside the stream (wave-uniform; every tile but a stream's last few): no guards,
       // two phases per register, the pair shifted by one sample from v_alignbit, two wrapped differences per v_pk_sub_i16
+        u32x4    x[2];
+        uint32_t after; // the sample behind the tile: only lane 63 of round 1 uses it
+        x[0] = *reinterpret_cast<g_cu4>(in + base + 8ull * (uint64_t)lane), x[1] = *reinterpret_cast<g_cu4>(in + base + 8ull * (uint64_t)(lane + 64));
+        after = in[base + (uint64_t)kUatTile];
         uint32_t p[2][4];
 #pragma unroll
         for (int r = 0; r < 2; r++)
         {
-            const uint4    x    = *reinterpret_cast<const uint4*>(in + base + 8ull * (uint64_t)(lane + 64 * r));
-            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+            const uint32_t w[4] = {x[r].x, x[r].y, x[r].z, x[r].w};
 #pragma unroll
             for (int k = 0; k < 4; k++)
             {
                 if (PHASES_GIVEN) p[r][k] = w[k];
                 else
                 {
-                    const char*    b  = reinterpret_cast<const char*>(lut);
-                    const uint32_t lo = *reinterpret_cast<const uint16_t*>(b + table_offset_lo(w[k]));
-                    const uint32_t hi = *reinterpret_cast<const uint16_t*>(b + table_offset_hi(w[k]));
+                    const auto     b  = reinterpret_cast<__attribute__((address_space(1))) const char*>(lut);
+                    const uint32_t lo = *reinterpret_cast<g_cu16>(b + table_offset_lo(w[k]));
+                    const uint32_t hi = *reinterpret_cast<g_cu16>(b + table_offset_hi(w[k]));
                     p[r][k]           = __builtin_amdgcn_perm(hi, lo, 0x05040100u); // hi.word0 : lo.word0
                 }
             }
         }
-        const uint32_t after = in[base + (uint64_t)kUatTile]; // only lane 63 of round 1 uses it
         const uint32_t after_ph = PHASES_GIVEN ? after : (uint32_t)lut[after];
+        if (counter) ticket = draw_ticket(counter, lane);
 #pragma unroll
         for (int r = 0; r < 2; r++)
         {
@@ -498,11 +526,12 @@ __device__ __noinline__ void stage_dphi(const uint16_t* __restrict__ in, const u
             const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp((int)wrap, (int)p[r][0], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
             const uint32_t p12 = __builtin_amdgcn_alignbit(p[r][1], p[r][0], 16), p34 = __builtin_amdgcn_alignbit(p[r][2], p[r][1], 16);
             const uint32_t p56 = __builtin_amdgcn_alignbit(p[r][3], p[r][2], 16), p78 = __builtin_amdgcn_alignbit(next, p[r][3], 16);
-            *reinterpret_cast<uint4*>(dphi_s + 8 * (lane + 64 * r)) =
-                make_uint4(pk_sub_i16(p12, p[r][0]), pk_sub_i16(p34, p[r][1]), pk_sub_i16(p56, p[r][2]), pk_sub_i16(p78, p[r][3]));
+            *reinterpret_cast<lds_u4>(dphi_s + 8 * (lane + 64 * r)) =
+                u32x4{pk_sub_i16(p12, p[r][0]), pk_sub_i16(p34, p[r][1]), pk_sub_i16(p56, p[r][2]), pk_sub_i16(p78, p[r][3])};
         }
-        return;
+        return ticket;
     }
+    if (counter) ticket = draw_ticket(counter, lane);
     uint32_t ph[2][8];
 #pragma unroll
     for (int r = 0; r < 2; r++)
@@ -528,8 +557,9 @@ __device__ __noinline__ void stage_dphi(const uint16_t* __restrict__ in, const u
             const uint32_t to = k < 7 ? ph[r][k + 1] : next;
             d[k]              = (s + (uint64_t)k + 1 < n) ? ((to - ph[r][k]) & 0xFFFFu) : 0u;
         }
-        *reinterpret_cast<uint4*>(dphi_s + 8 * (lane + 64 * r)) = make_uint4(d[0] | d[1] << 16, d[2] | d[3] << 16, d[4] | d[5] << 16, d[6] | d[7] << 16);
+        *reinterpret_cast<lds_u4>(dphi_s + 8 * (lane + 64 * r)) = u32x4{d[0] | d[1] << 16, d[2] | d[3] << 16, d[4] | d[5] << 16, d[6] | d[7] << 16};
     }
+    return ticket;
 }
 
 // the sync re-check, the sign windows and the slicing on the staged tile; `off` = the first sample's index inside the tile
@@ -902,19 +932,27 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
     const uint32_t nup    = up_list ? *up_count : 0u;
     const uint32_t nup_r  = nup > range ? (nup - range + nranges - 1) / nranges : 0u;
     const uint32_t nitems = nup_r + (end - first);
+    const g_u32    my_counter = (g_u32)&work_counters[range * 32u];
     UAT_DIAG_DECLARE();
     for (uint32_t item = slot; item < nitems;)
     {
-        uint32_t grabbed = 0;
-        if (lane == 0) grabbed = atomicAdd(&work_counters[range * 32u], 1u); // used at the end of the trip
-        const uint32_t next_item = nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)grabbed);
         const bool     from_list = item < nup_r;
         const uint32_t c         = from_list ? up_list[range + item * nranges] : first + (item - nup_r);
-        item                     = next_item;
         uint32_t   word = cand ? cand[c] : single_word; // cand == nullptr: one look-up the host asked for, passed by value
         uat_rec_t* r    = &recs[c];
         uint8_t*   pay  = payloads + (size_t)c * kUatPayloadStride;
-        if (!from_list && (word >> 31) && up_list) continue; // an uplink match inside the slice: taken in the first phase
+        if (!from_list && (word >> 31) && up_list)
+        { // an uplink match inside the slice: taken in the first phase
+            item = nslot + draw_ticket(my_counter, lane);
+            continue;
+        }
+        // The ticket for the wave's next match is drawn inside the staging of this one's first tile (stage_dphi): the atomic's round trip
+        // to the memory side runs beside the tile's loads instead of being a wait of its own at the head of every match.  (That staging
+        // stands in front of the loop over positions so that the ticket is a value of THIS loop: the inner one's exits count as
+        // lane-varying, and a value carried through it would live in a vector register.)
+        wave_fence(); // the previous match's readers are done with the tile
+        const uint32_t next_item = nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_dphi<PHASES_GIVEN>(
+                                               (g_cu16)in, (g_cu16)lut, n, (uint64_t)(word & 0x7FFFFFF8u), (lds_i16)dphi_s, lane, my_counter));
         // After the match's own frame: the frames the scan loop would take behind it through stale register bits (see StaleWindow).
         // They are demodulated by this wave, by the same code: the body below runs once per position.  All of this is wave-uniform.
         StaleWindow stale;
@@ -929,8 +967,11 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
         const int      o    = (int)(idx - base);          // the match's first sync sample inside tile 0 (0 .. 8)
         const int      oe   = (int)(2 * sb - base);       // the same, forced even: what the two shift registers are aligned to
         UAT_DIAG_BEGIN();
-        wave_fence(); // the previous candidate's readers are done with the tile
-        stage_dphi<PHASES_GIVEN>(in, lut, n, base, dphi_s, lane);
+        if (chained)
+        {
+            wave_fence(); // the previous position's readers are done with the tile
+            stage_dphi<PHASES_GIVEN>((g_cu16)in, (g_cu16)lut, n, base, (lds_i16)dphi_s, lane, (g_u32) nullptr);
+        }
         wave_fence();
         UAT_DIAG_LAP(kDiagStage);
         const uint64_t w0 = sign_window_tile(dphi_s, oe, lane);
@@ -995,7 +1036,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
                     if (t > 0)
                     {
                         wave_fence();
-                        stage_dphi<PHASES_GIVEN>(in, lut, n, base + (uint64_t)(t * kUatTileStride), dphi_s, lane);
+                        stage_dphi<PHASES_GIVEN>((g_cu16)in, (g_cu16)lut, n, base + (uint64_t)(t * kUatTileStride), (lds_i16)dphi_s, lane, (g_u32) nullptr);
                         wave_fence();
                         UAT_DIAG_LAP(kDiagMoreTiles);
                     }
@@ -1117,6 +1158,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
         seq++;
         word = at | (k2 << 31), r = &extras[x].rec, pay = extra_payloads + (size_t)x * kUatPayloadStride, chained = true;
         }
+        item = next_item;
     }
     UAT_DIAG_FLUSH();
 }

@@ -1,4 +1,3 @@
-python3 -m pytest tests -x -q -m gpu > gpurun_out/r04_t29.log 2>&1; tail -2 gpurun_out/r04_t29.log
-python3 bench.py --steps 20 --warmup 5 --no-extras --cpu-buffers 0 2>/dev/null | python3 -c "
-import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
+set -o pipefail
+timeout -k 10 500 python -m pytest tests/test_uat978_gpu.py -x -q -m gpu > gpurun_out/r04_uat_t2.log 2>&1; echo "tests rc=$?" ; tail -3 gpurun_out/r04_uat_t2.log
+timeout -k 10 500 python tools/uat_ab.py ab_libs/u_base.so ab_libs/u_t2.so ab_libs/u_base.so ab_libs/u_t2.so > gpurun_out/r04_uat_ab2.txt 2>&1; cat gpurun_out/r04_uat_ab2.txt
