@@ -479,7 +479,7 @@ __device__ __forceinline__ uint32_t draw_ticket(g_u32 counter, int lane)
 }
 
 template <bool PHASES_GIVEN>
-__device__ __noinline__ uint32_t stage_dphi(g_cu16 in, g_cu16 lut, uint64_t n, uint64_t base, lds_i16 dphi_s, int lane, g_u32 counter)
+__device__ __forceinline__ uint32_t stage_dphi_body(g_cu16 in, g_cu16 lut, uint64_t n, uint64_t base, lds_i16 dphi_s, int lane, g_u32 counter)
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); // (HIP's uint4 is a class: no assignment across address spaces)
     typedef __attribute__((address_space(1))) const u32x4* g_cu4;
@@ -562,6 +562,12 @@ __device__ __noinline__ uint32_t stage_dphi(g_cu16 in, g_cu16 lut, uint64_t n, u
     return ticket;
 }
 
+template <bool PHASES_GIVEN>
+__device__ __noinline__ uint32_t stage_dphi(g_cu16 in, g_cu16 lut, uint64_t n, uint64_t base, lds_i16 dphi_s, int lane, g_u32 counter)
+{
+    return stage_dphi_body<PHASES_GIVEN>(in, lut, n, base, dphi_s, lane, counter);
+}
+
 // the sync re-check, the sign windows and the slicing on the staged tile; `off` = the first sample's index inside the tile
 __device__ __forceinline__ SyncCheck check_sync_tile(const int16_t* dphi_s, int off, bool uplink, int lane)
 {
@@ -612,6 +618,11 @@ __device__ __forceinline__ void slice_bytes_tile(const int16_t* dphi_s, int off0
     }
 }
 
+// Behind an `if (lane == 0) store;` that is followed by a jump (break): keeps the two paths' meeting point a block of its own.  Without it
+// the compiler folds that meeting point into the jump's target, the target's phi nodes then have the lane-dependent branch among their
+// predecessors, and every value carried through them (all of the demodulating wave's uniform state) counts as lane-varying: vector
+// registers and exec-mask branches instead of scalar ones.  No instruction is emitted for it.
+__device__ __forceinline__ void lane0_join() { __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"), __builtin_amdgcn_wave_barrier(), __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
 // ---- Reed-Solomon with the whole wave on one code word.  Same procedure and same results as rs978_decode_with_syndromes
@@ -646,8 +657,15 @@ __device__ __forceinline__ int mod255_16(int x)
 }
 typedef __attribute__((address_space(3))) const uint8_t* lds_cu8; // kept out of line (registers), so the address space has to be spelled out
 typedef __attribute__((address_space(3))) uint8_t*       lds_u8;
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class P>
+__device__ __forceinline__ P uni_lds(P p)
+{ // a function's arguments arrive in vector registers; what is the same in every lane is said to be so: scalar loop control, scalar bases
+    return (P)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
+}
 __device__ __noinline__ void syndromes_lds(lds_cu8 exp_t, lds_cu8 log_t, int nr, int n, lds_cu8 data, int stride, lds_u8 out, int lane)
 {
+    exp_t = uni_lds(exp_t), log_t = uni_lds(log_t), data = uni_lds(data), out = uni_lds(out), nr = uni(nr), n = uni(n), stride = uni(stride);
     const bool     two = n > 64; // uniform
     const int      j0 = lane, j1 = lane + 64;
     const uint32_t d0 = j0 < n ? data[j0 * stride] : 0u, d1 = (two && j1 < n) ? data[j1 * stride] : 0u;
@@ -685,6 +703,7 @@ __device__ __forceinline__ void syndromes_wave(const RsTables& T, int nr, int n,
 typedef __attribute__((address_space(3))) RsWork* lds_work;
 __device__ __noinline__ int rs_decode_lds(lds_cu8 exp_t, lds_cu8 log_t, int nr, int pad, lds_u8 data, int stride, lds_work wp, int lane)
 {
+    exp_t = uni_lds(exp_t), log_t = uni_lds(log_t), data = uni_lds(data), wp = uni_lds(wp), nr = uni(nr), pad = uni(pad), stride = uni(stride);
     auto& w = *wp;
     struct
     {
@@ -790,14 +809,15 @@ __device__ __noinline__ int rs_decode_lds(lds_cu8 exp_t, lds_cu8 log_t, int nr, 
 
 __device__ __forceinline__ int rs_decode_wave(const RsTables& T, int nr, int pad, uint8_t* data, int stride, RsWork& w, int lane)
 {
-    return rs_decode_lds((lds_cu8)T.exp, (lds_cu8)T.log, nr, pad, (lds_u8)data, stride, (lds_work)&w, lane);
+    // (the same in every lane, but a function's result counts as lane-varying: said here, the caller's loop control stays on the scalar unit)
+    return __builtin_amdgcn_readfirstlane(rs_decode_lds((lds_cu8)T.exp, (lds_cu8)T.log, nr, pad, (lds_u8)data, stride, (lds_work)&w, lane));
 }
 
 // correct_adsb_frame with the wave on one slicing: w.s = the 14 long syndromes.  Returns the bits to jump (0 = neither); *rs = corrected symbols (9999 = neither).  Uniform.
 __device__ int correct_adsb_wave(const RsTables& T, uint8_t* frame48, RsWork& w, int lane, int* rs)
 {
     int n = rs_decode_wave(T, 14, 207, frame48, 1, w, lane);
-    if (n >= 0 && n <= 7 && (frame48[0] >> 3) != 0)
+    if (n >= 0 && n <= 7 && __builtin_amdgcn_readfirstlane(frame48[0] >> 3) != 0)
     {
         *rs = n;
         return kUatLongSkip;
@@ -805,7 +825,7 @@ __device__ int correct_adsb_wave(const RsTables& T, uint8_t* frame48, RsWork& w,
     syndromes_wave(T, 12, 30, frame48, 1, w.s, lane); // only now: most frames are long and never get here
     wave_fence();
     n = rs_decode_wave(T, 12, 225, frame48, 1, w, lane);
-    if (n >= 0 && n <= 6 && (frame48[0] >> 3) == 0)
+    if (n >= 0 && n <= 6 && __builtin_amdgcn_readfirstlane(frame48[0] >> 3) == 0)
     {
         *rs = n;
         return kUatShortSkip;
@@ -899,8 +919,11 @@ __device__ unsigned long long g_uat_diag[2][8]; // [kind][phase]; phase 7 = posi
 #endif
 enum { kDiagStage = 0, kDiagSync, kDiagSlice, kDiagSyndromes, kDiagDecode, kDiagMoreTiles, kDiagOutput };
 
+#ifndef ADSB_AMD_UAT_STAGE_INLINE
+#define ADSB_AMD_UAT_STAGE_INLINE 0
+#endif
 #ifndef ADSB_AMD_UAT_DEMOD_WAVES
-#define ADSB_AMD_UAT_DEMOD_WAVES 6
+#define ADSB_AMD_UAT_DEMOD_WAVES 8
 #endif
 template <bool PHASES_GIVEN>
 __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
@@ -951,7 +974,12 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
         // stands in front of the loop over positions so that the ticket is a value of THIS loop: the inner one's exits count as
         // lane-varying, and a value carried through it would live in a vector register.)
         wave_fence(); // the previous match's readers are done with the tile
-        const uint32_t next_item = nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_dphi<PHASES_GIVEN>(
+#if ADSB_AMD_UAT_STAGE_INLINE
+#define UAT_STAGE_FIRST stage_dphi_body
+#else
+#define UAT_STAGE_FIRST stage_dphi
+#endif
+        const uint32_t next_item = nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)UAT_STAGE_FIRST<PHASES_GIVEN>(
                                                (g_cu16)in, (g_cu16)lut, n, (uint64_t)(word & 0x7FFFFFF8u), (lds_i16)dphi_s, lane, my_counter));
         // After the match's own frame: the frames the scan loop would take behind it through stale register bits (see StaleWindow).
         // They are demodulated by this wave, by the same code: the body below runs once per position.  All of this is wave-uniform.
@@ -1007,10 +1035,12 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
                 if (v == 0)
                 { // the decoders correct in place
                     if (lane < kUatLongBytes) sliced[lane] = raw[0][lane];
+                    lane0_join();
                     sliced0 = true;
                 }
                 int       rs_v   = 9999;
-                const int skip_v = correct_adsb_wave(T, raw[v], work[v], lane, &rs_v);
+                const int skip_v = __builtin_amdgcn_readfirstlane(correct_adsb_wave(T, raw[v], work[v], lane, &rs_v));
+                rs_v             = __builtin_amdgcn_readfirstlane(rs_v);
                 UAT_DIAG_LAP(kDiagDecode);
                 if (v == 0) skip0 = skip_v, rs0 = rs_v;
                 else skip1 = skip_v, rs1 = rs_v;
@@ -1058,8 +1088,8 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
                 // both alignments sliced to the same 552 bytes: they decode alike, the tie goes to variant 0 (as for ADS-B above)
                 bool same = ok[0] && ok[1];
 #pragma unroll 1
-                for (int k = lane; same && k < kUatUplinkBytes + 64 - kUatUplinkBytes % 64; k += 64)
-                    same = __ballot(k < kUatUplinkBytes && raw[0][k] != raw[1][k]) == 0;
+                for (int k0 = 0; same && k0 < kUatUplinkBytes; k0 += 64) // (a scalar counter: a loop left on a lane's own counter makes `same` lane-varying for the compiler)
+                    same = __ballot(k0 + lane < kUatUplinkBytes && raw[0][k0 + lane] != raw[1][k0 + lane]) == 0;
 #pragma unroll 1
                 for (int v = 0; v < 2; v++)
                 {
@@ -1106,8 +1136,13 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
                 up_slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
                 if (up_slot < uplink_cap)
                     for (int k = lane; k < 432; k += 64) uplink_payloads[(size_t)up_slot * 432 + k] = raw[v_take][(k % 72) * 6 + k / 72];
+                lane0_join();
             }
-            else if (lane < 34) pay[lane] = raw[v_take][lane];
+            else
+            {
+                if (lane < 34) pay[lane] = raw[v_take][lane];
+                lane0_join();
+            }
         }
         const uint64_t after = (kind || skip_t == kUatShortSkip) ? w1 : w2; // what enters the registers after the jump
         if (lane == 0)
@@ -1121,12 +1156,17 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
         UAT_DIAG_LAP(kDiagOutput);
         UAT_DIAG_END(kind);
         if (!next_bit) break; // a single look-up: the host follows the loop itself
-        if (kind && v_take < 2 && up_slot >= uplink_cap && lane == 0) counts[kUatCountOverflow] = 1;
+        if (kind && v_take < 2 && up_slot >= uplink_cap)
+        {
+            if (lane == 0) counts[kUatCountOverflow] = 1;
+            lane0_join();
+        }
         if (!chained)
         {
             if (v_take == 2)
             { // no frame at this match: the loop moves on bit by bit
                 if (lane == 0) next_bit[c] = 0;
+                lane0_join();
                 break;
             }
             stale.jump((uint32_t)w0 & kCheckMask, (uint32_t)(w0 >> 32) & kCheckMask, after, (int64_t)sb + skip_t + 1, lenbits, lane);
@@ -1137,6 +1177,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
         { // both registers hold 18 new bits again 17 bits on; a jump past the end of the scanned part stays where it is
             const int64_t nb = stale.bit < lenbits ? (stale.bit + 17 < lenbits ? stale.bit + 17 : lenbits) : stale.bit;
             if (lane == 0) next_bit[c] = (uint32_t)nb;
+            lane0_join();
             break;
         }
         // the first step that fires: position and check word as the loop derives them
@@ -1152,6 +1193,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
         if (x >= extra_cap)
         { // no room: the host will walk the loop itself for this call
             if (lane == 0) counts[kUatCountOverflow] = 1, next_bit[c] = 0;
+            lane0_join();
             break;
         }
         if (lane == 0) extras[x].parent = c, extras[x].seq = seq;

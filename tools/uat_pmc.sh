@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 out=$PWD/gpurun_out/uat_pmc; rm -rf $out; mkdir -p $out
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $GRAFT_REPO_ROOT/tools/uat_rate.py --reps 5 --no-cpu > $out/log_trace 2>&1)
 i=0
-for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM"; do
   i=$((i+1))
   (cd /tmp && rocprofv3 --pmc $set --output-format csv -d $out/pmc$i -- python3 $GRAFT_REPO_ROOT/tools/uat_rate.py --reps 2 --no-cpu > $out/log_pmc$i 2>&1) || echo "pass $i failed"
 done
