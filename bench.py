@@ -888,12 +888,12 @@ def bench_uat978(args, rank, local_rank, world, dist, A, synth, torch):
             "host_wall_ms_last_step": tm["host_wall_ms"],
         }
         if demod_k > scan_k:
-            # per-match kernel, instruction-bound (PMC, profiles/r03_uat978_rocprof_summary.txt): its algorithmic bytes are the phases of
+            # per-match kernel, instruction-bound (PMC, profiles/r04_uat978_rocprof_summary.txt): its algorithmic bytes are the phases of
             # the matches' frames, far below any HBM bound
             out["dominant_kernel"] = {"kernel": "uat_demod_kernel", "kernel_ms": round(demod_k, 4), "matches": int(matches),
                                       "us_per_1000_matches": round(demod_k * 1e3 / max(1, matches) * 1e3, 2),
                                       "note": "dominant by time; instruction-bound (sync re-check, slicing, Reed-Solomon per match; counters in "
-                                              "profiles/r03_uat978_rocprof_summary.txt), not bandwidth-bound: the HBM roofline "
+                                              "profiles/r04_uat978_rocprof_summary.txt), not bandwidth-bound: the HBM roofline "
                                               "above is the scan kernel's, the only kernel of this path that streams the input"}
         if world == 1 and args.cpu_buffers > 0:
             from oracle import oracle_py as O
