@@ -1,2 +1,6 @@
 set -o pipefail
-timeout -k 10 600 python tools/uat_ab.py ab_libs/u_h8.so ab_libs/u_n8.so ab_libs/u_h8.so ab_libs/u_n8.so > gpurun_out/r04_uat_ab6.txt 2>&1; cat gpurun_out/r04_uat_ab6.txt
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+for n in 2 4; do
+timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29500+n)) bench.py --gpus $n --steps 10 --warmup 3 --rehearse-on-one-gpu > gpurun_out/r04_rehearse_n$n.json 2> gpurun_out/r04_rehearse_n$n.err; echo "n=$n rc=$?"; tail -1 gpurun_out/r04_rehearse_n$n.json | python3 -c "
+import json,sys;d=json.loads(sys.stdin.read());print(d['n_gpus'],d['value'],d['ms_per_step'],d.get('ranks_seen'),d.get('scaling'))"
+done
