@@ -645,6 +645,14 @@ __device__ __forceinline__ int wave_xor_i(int x)
     x ^= dpp_or_zero_x<0x143, 0xC>(x);
     return __builtin_amdgcn_readlane(x, 63);
 }
+__device__ __forceinline__ int row0_xor_i(int x)
+{ // XOR over lanes 0 .. 15 only
+    x ^= dpp_or_zero_x<0x111, 0xF>(x);
+    x ^= dpp_or_zero_x<0x112, 0xF>(x);
+    x ^= dpp_or_zero_x<0x114, 0xF>(x);
+    x ^= dpp_or_zero_x<0x118, 0xF>(x);
+    return __builtin_amdgcn_readlane(x, 15);
+}
 __device__ __forceinline__ int      gf_fold(int x) { return (x & 255) + (x >> 8); } // == x mod 255 as an index into exp[] (< 510 for x < 65536)
 
 // The nr syndromes of the n symbols data[0], data[stride], ... with the wave across the symbols instead of Horner's n dependent
@@ -698,6 +706,55 @@ __device__ __forceinline__ void syndromes_wave(const RsTables& T, int nr, int n,
     syndromes_lds((lds_cu8)T.exp, (lds_cu8)T.log, nr, n, (lds_cu8)data, stride, (lds_u8)out, lane);
 }
 
+// The same for the code that nearly every match asks for first -- the 14 syndromes of 48 bytes (RS(48,34)) -- with the exponents
+// (fcr + i)(n - 1 - lane) mod 255 kept in registers for the whole launch (syndrome_exponents; likewise the 12 of 30 bytes): a syndrome
+// costs one address add and one table look-up instead of the six instructions of stepping the exponent modulo 255, and the test for a zero
+// byte is made once per four syndromes.  Same values as syndromes_lds(14, 48, stride 1) (tests: every stream comparison goes through it).
+template <int GROUPS>
+struct CodeExponents
+{
+    uint32_t pk[GROUPS]; // byte i % 4 of pk[i / 4] = (fcr + i)(n - 1 - lane) mod 255
+};
+template <int N, int GROUPS>
+__device__ __forceinline__ CodeExponents<GROUPS> syndrome_exponents(int lane)
+{
+    CodeExponents<GROUPS> x;
+    const uint32_t        p = lane < N ? (uint32_t)(N - 1 - lane) : 0u;
+    uint32_t              e = (uint32_t)mod255_16(kRsFcr * (int)p);
+    e                       = __builtin_elementwise_min(e, e - 255u);
+#pragma unroll
+    for (int g = 0; g < GROUPS; g++)
+    {
+        uint32_t w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            w |= e << (8 * k);
+            e += p, e = __builtin_elementwise_min(e, e - 255u);
+        }
+        x.pk[g] = w;
+    }
+    return x;
+}
+typedef CodeExponents<4> LongExponents;  // RS(48,34): 14 syndromes
+typedef CodeExponents<3> ShortExponents; // RS(30,18): 12 syndromes
+template <int N, int NR, int GROUPS>
+__device__ __forceinline__ void syndromes_fixed_wave(const RsTables& T, const uint8_t* data, uint8_t* out, int lane, const CodeExponents<GROUPS>& x)
+{
+    static_assert(4 * GROUPS >= NR && N <= 64, "one byte per lane, four syndromes per register");
+    const uint32_t d  = lane < N ? (uint32_t)data[lane] : 0u;
+    const uint8_t* eb = T.exp + T.log[d]; // (log[0] = 0: a zero byte's terms are dropped below)
+#pragma unroll
+    for (int g = 0; g < GROUPS; g++)
+    {
+        const uint32_t w      = x.pk[g];
+        uint32_t       packed = (uint32_t)eb[w & 255u] | (uint32_t)eb[(w >> 8) & 255u] << 8 | (uint32_t)eb[(w >> 16) & 255u] << 16 | (uint32_t)eb[w >> 24] << 24;
+        packed                = d ? packed : 0u;
+        const uint32_t red    = (uint32_t)wave_xor_i((int)packed);
+        if (lane < 4 && 4 * g + lane < NR) out[4 * g + lane] = (uint8_t)(red >> (8 * lane));
+    }
+}
+
 // Kept out of line (three call sites: long and short ADS-B code, uplink blocks; inlined copies cost the kernel a wave of occupancy), so
 // the LDS address space of its operands is spelled out as for syndromes_lds.
 typedef __attribute__((address_space(3))) RsWork* lds_work;
@@ -728,7 +785,7 @@ __device__ __noinline__ int rs_decode_lds(lds_cu8 exp_t, lds_cu8 log_t, int nr, 
         sv  = (uint32_t)__builtin_amdgcn_update_dpp((int)s_new, (int)sv, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
         lsv = (uint32_t)__builtin_amdgcn_update_dpp((int)ls_new, (int)lsv, 0x138, 0xF, 0xF, false);
         const uint32_t term   = (lam && sv) ? (uint32_t)T.exp[llam + lsv] : 0u;
-        const uint32_t discr  = (uint32_t)wave_xor_i((int)term);
+        const uint32_t discr  = (uint32_t)(nr <= 15 ? row0_xor_i((int)term) : wave_xor_i((int)term)); // nr + 1 coefficients: lanes above hold zero
         const uint32_t bs_nz  = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bnz, 0x138, 0xF, 0xF, false);
         const uint32_t lbs    = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lbb, 0x138, 0xF, 0xF, false);
         if (discr == 0) bnz = bs_nz, lbb = lbs;
@@ -814,7 +871,7 @@ __device__ __forceinline__ int rs_decode_wave(const RsTables& T, int nr, int pad
 }
 
 // correct_adsb_frame with the wave on one slicing: w.s = the 14 long syndromes.  Returns the bits to jump (0 = neither); *rs = corrected symbols (9999 = neither).  Uniform.
-__device__ int correct_adsb_wave(const RsTables& T, uint8_t* frame48, RsWork& w, int lane, int* rs)
+__device__ __forceinline__ int correct_adsb_wave(const RsTables& T, uint8_t* frame48, RsWork& w, int lane, int* rs, const ShortExponents* short_exp = nullptr)
 {
     int n = rs_decode_wave(T, 14, 207, frame48, 1, w, lane);
     if (n >= 0 && n <= 7 && __builtin_amdgcn_readfirstlane(frame48[0] >> 3) != 0)
@@ -822,7 +879,8 @@ __device__ int correct_adsb_wave(const RsTables& T, uint8_t* frame48, RsWork& w,
         *rs = n;
         return kUatLongSkip;
     }
-    syndromes_wave(T, 12, 30, frame48, 1, w.s, lane); // only now: most frames are long and never get here
+    if (short_exp) syndromes_fixed_wave<30, 12>(T, frame48, w.s, lane, *short_exp); // only now: most frames are long and never get here
+    else syndromes_wave(T, 12, 30, frame48, 1, w.s, lane);
     wave_fence();
     n = rs_decode_wave(T, 12, 225, frame48, 1, w, lane);
     if (n >= 0 && n <= 6 && __builtin_amdgcn_readfirstlane(frame48[0] >> 3) == 0)
@@ -923,7 +981,7 @@ enum { kDiagStage = 0, kDiagSync, kDiagSlice, kDiagSyndromes, kDiagDecode, kDiag
 #define ADSB_AMD_UAT_STAGE_INLINE 0
 #endif
 #ifndef ADSB_AMD_UAT_DEMOD_WAVES
-#define ADSB_AMD_UAT_DEMOD_WAVES 8
+#define ADSB_AMD_UAT_DEMOD_WAVES 7
 #endif
 template <bool PHASES_GIVEN>
 __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
@@ -956,6 +1014,8 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
     const uint32_t nup_r  = nup > range ? (nup - range + nranges - 1) / nranges : 0u;
     const uint32_t nitems = nup_r + (end - first);
     const g_u32    my_counter = (g_u32)&work_counters[range * 32u];
+    const LongExponents  long_exp  = syndrome_exponents<48, 4>(lane);
+    const ShortExponents short_exp = syndrome_exponents<30, 3>(lane);
     UAT_DIAG_DECLARE();
     for (uint32_t item = slot; item < nitems;)
     {
@@ -1029,7 +1089,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
                     skip1 = skip0, rs1 = rs0;
                     break;
                 }
-                syndromes_wave(T, 14, 48, raw[v], 1, work[v].s, lane);
+                syndromes_fixed_wave<48, 14>(T, raw[v], work[v].s, lane, long_exp);
                 wave_fence();
                 UAT_DIAG_LAP(kDiagSyndromes);
                 if (v == 0)
@@ -1039,7 +1099,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
                     sliced0 = true;
                 }
                 int       rs_v   = 9999;
-                const int skip_v = __builtin_amdgcn_readfirstlane(correct_adsb_wave(T, raw[v], work[v], lane, &rs_v));
+                const int skip_v = __builtin_amdgcn_readfirstlane(correct_adsb_wave(T, raw[v], work[v], lane, &rs_v, &short_exp));
                 rs_v             = __builtin_amdgcn_readfirstlane(rs_v);
                 UAT_DIAG_LAP(kDiagDecode);
                 if (v == 0) skip0 = skip_v, rs0 = rs_v;
