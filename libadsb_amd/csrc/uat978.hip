@@ -1555,7 +1555,10 @@ __global__ __launch_bounds__(kUatDecideThreads) void uat_mark_kernel(uint32_t n,
     // The bit map of this block's matches is put together in LDS and goes out with one atomic per word: device-scope atomics are
     // performed past the XCD's L2 (one per frame taken, 74 000 per GiB, made this kernel 64 us long).  A start bit's second match
     // can be the first match of the next block, hence one word more than the block has, and atomics rather than stores.
-    __shared__ uint32_t map[kUatDecideNodes / 32 + 1];
+    // (It lives where the hop tables were -- nobody reads them after the last level: 20 480 bytes in all, which is what seven demodulating
+    // waves per SIMD leave free on a CU, so this workgroup can run beside another call's demodulation kernel.)
+    uint32_t* const map = reinterpret_cast<uint32_t*>(&hop[0][0]);
+    static_assert(sizeof(hop) >= (kUatDecideNodes / 32 + 1) * sizeof(uint32_t), "the bit map fits where the tables were");
     if (threadIdx.x < kUatDecideNodes / 32 + 1) map[threadIdx.x] = 0;
     __syncthreads();
     uint32_t taken = 0, last = 0;
@@ -1627,7 +1630,7 @@ hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, bool ordered, h
 {
     if (ncand == 0) return hipSuccess;
     const uint32_t nranges = ncand >= 4096 ? kUatDemodRanges : 1u;
-    uint32_t       g       = ncand > 8192 ? 8192 : ncand;
+    uint32_t       g       = ncand > 8192 ? 8192 : ncand; // (exactly as many workgroups as the device holds at once -- 7168 -- measured: no better)
     g                      = ((g + nranges - 1) / nranges) * nranges;
     if (!ordered && ncand > 1)
     { // (a single look-up needs no reset: one wave, one item, and the loop ends whatever the counter holds; the next ordering pass zeroes it)

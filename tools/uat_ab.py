@@ -9,7 +9,7 @@ import sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for lib in sys.argv[1:]:
     env = dict(os.environ, ADSB_AMD_LIB=os.path.join(root, lib))
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "uat978", "--steps", "20", "--warmup", "3", "--cpu-buffers", "0"],
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "uat978", "--steps", os.environ.get("AB_STEPS", "20"), "--warmup", "3", "--cpu-buffers", "0"],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
     d = json.loads(out.strip().splitlines()[-1])
     print("%-22s step %.4f ms  serial %.4f  scan %.4f  demod %.4f  host %s" % (lib, d["ms_per_step"], d["ms_per_step_serial"], d["roofline"]["kernel_ms"],
