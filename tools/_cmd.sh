@@ -1,3 +1,3 @@
 set -o pipefail
-export AB_STEPS=40
-timeout -k 10 900 python tools/uat_ab.py ab_libs/u_m7.so ab_libs/u_g7.so ab_libs/u_m7.so ab_libs/u_g7.so > gpurun_out/r04_uat_ab10.txt 2>&1; cat gpurun_out/r04_uat_ab10.txt
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r04_full_t10.log 2>&1; echo "tests rc=$?" ; tail -2 gpurun_out/r04_full_t10.log
+(timeout -k 10 900 python tools/fuzz_many.py 3000 1500 800 ; timeout -k 10 400 python tools/fuzz_parts.py 300) > gpurun_out/r04_fuzz_final.txt 2>&1; echo "fuzz rc=$?"; grep -v amdgpu.ids gpurun_out/r04_fuzz_final.txt | tail -7
