@@ -25,6 +25,7 @@
 
 #include "adsb_amd.h"
 #include "decode1090.h"
+#include "diag.hip.h"
 #include "resolver1090.hpp"
 #include "scan1090.h"
 #include "transport.hpp"
@@ -37,7 +38,7 @@ thread_local std::string g_create_error;
 
 struct Slot
 {
-    uint32_t*          counts   = nullptr; // the chunk directory: {first raw record, records kept} per chunk
+    uint32_t*          counts   = nullptr; // the chunk directory: records kept per chunk
     uint32_t*          block_sums = nullptr; // two arrays of one padded entry per 256 chunks: the scan adds into one, the ordering pass zeroes the other
     size_t             sums_words = 0;       // words per array
     int                sums_phase = 0;       // which array the next scan uses
@@ -48,7 +49,7 @@ struct Slot
     unsigned            produced = 0;      // ADSB_AMD_OUT_* of the slot's last scan: the context's mask when it was SUBMITTED (a repeat after an overflow keeps it)
     uint32_t*          total_d  = nullptr; // device {total, overflow}
     uint32_t*          work_d   = nullptr; // device: one chunk counter per XCD (scan1090_kernel), zero between scans
-    unsigned long long* total_h = nullptr; // page-locked: {total, overflow} as two words (copied), or count | (stamp << 1 | overflow) << 32 (kCountHost)
+    unsigned long long* total_h = nullptr; // page-locked: count | (stamp << 1 | overflow) << 32, stored by the ordering pass
     unsigned long long* total_h_dev = nullptr; // the device's address of it
     adsb_amd_record_t* host     = nullptr; // pinned result
     adsb_amd_decoded_t* host_dec = nullptr; // pinned, parallel to host (same capacity)
@@ -57,8 +58,8 @@ struct Slot
     size_t             host_cap = 0;       // records
     size_t             chunks_cap = 0, cap_per_chunk = 0;
     size_t             cap_hint = 0;       // region size the other slot had to grow to: this slot's next scan starts with it
-    hipEvent_t         ev_scan0 = nullptr, ev_scan1 = nullptr, ev_order = nullptr, ev_done = nullptr;
-    uint32_t           seq = 0;            // launches of this slot: the stamp the ordering pass writes beside the count (kCountHost)
+    hipEvent_t         ev_scan0 = nullptr, ev_scan1 = nullptr, ev_order = nullptr;
+    uint32_t           seq = 0;            // launches of this slot: the stamp the ordering pass writes beside the count
     bool               pending = false, timed = false;
     bool               events = false;     // this scan has the two timing events around its kernel
     // the submitted job (needed again when a chunk region overflows and the scan is repeated with a larger cap)
@@ -75,7 +76,7 @@ struct adsb_amd_ctx
     int         device = 0;
     int         mode   = ADSB_AMD_MODE_2000;
     uint32_t    nxcd = 8, ncu = 256; // topology of the device, read once at create
-    hipStream_t stream = nullptr, copy_stream = nullptr, ctl_stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
     uint32_t*   crc_tab = nullptr;
     uint16_t*   lut978  = nullptr;
     uint8_t*    staging = nullptr; // device copy of host input
@@ -83,14 +84,8 @@ struct adsb_amd_ctx
     Slot        slot[2];
     unsigned    outputs = ADSB_AMD_OUT_RECORDS | ADSB_AMD_OUT_DECODED; // arrays the ordering pass produces (adsb_amd_set_outputs)
     unsigned    timing_every = 1, submits = 0; // adsb_amd_set_timing
-    int         count_path = 0;                // how the record count reaches the host: count_path_from_env()
-#ifdef ADSB_AMD_STAMPS
-    unsigned long long* stamps_d = nullptr; // diagnostic builds: four clock values per launch, a ring of kStampSteps launches
+    unsigned long long* stamps_d = nullptr; // measurement builds (diag.hip.h): four clock values per wave and launch, a ring of kStampSteps launches
     unsigned            stamp_no = 0;
-#endif
-    bool        logs_ok = false; // raw records go to per-wave logs instead of per-chunk regions: ADSB_AMD_RECORD_LOGS=1.  Measured and not the
-                                 // default (profiles/r04_sweep.txt): the ordering pass reads the logs no faster once it has a lane per record, and
-                                 // the scan is 3 % slower with them (all waves' logs start at the same place modulo 32 KiB)
     std::string error;
 };
 
@@ -114,35 +109,14 @@ int fail(adsb_amd_ctx* c, int code, const char* msg)
 }
 
 constexpr uint32_t kDefaultCap = 32;
-#ifdef ADSB_AMD_STAMPS
-constexpr unsigned kStampSteps = 128, kStampGroups = 8192; // launches kept (a ring), workgroups per launch (scan_common.hip.h)
-#endif
+constexpr unsigned kStampSteps = 128, kStampGroups = 8192; // measurement builds: launches kept (a ring), workgroups per launch (scan_common.hip.h)
 
-// How the record count of a scan reaches the host.
-//   kCountHost   (default): the ordering pass's last workgroup writes {count, overflow flag, launch stamp} as ONE 8-byte system-scope store
-//                into page-locked host memory and the host polls the stamp; nothing but the two kernels is on the scan's stream, and the record
-//                copy (copy stream) waits for the pass's event on the device.
-//   kCountCtl:   an 8-byte copy + event on a control stream behind the pass's event.  Cheap on the scan's stream, but the runtime's copy of
-//                eight bytes is a kernel, and beside a scan kernel that keeps every vector unit busy (the 2.4 MS/s mode) it got onto the
-//                chip 0.1-0.2 ms late: the host then submitted the next scan late and the GPU idled 75 us per step.
-//   kCountStream: the round-3 form, copy + event on the scan's own stream (11 us of that stream per step).
-// ADSB_AMD_COUNT_PATH=host|ctl|stream selects (A/B and fault-finding).
-enum : int { kCountHost = 0, kCountCtl = 1, kCountStream = 2 };
-int count_path_from_env()
-{
-    const char* e = std::getenv("ADSB_AMD_COUNT_PATH");
-    if (e && !std::strcmp(e, "ctl")) return kCountCtl;
-    if (e && !std::strcmp(e, "stream")) return kCountStream;
-    return kCountHost;
-}
-
-// The event between the ordering pass and the count's copy on the control stream orders device work only (the copy that follows it is
-// what the host sees): no system-scope release.  ADSB_AMD_ORDER_EVENT_FENCE=1 gives it one (A/B and fault-finding).
-unsigned order_event_flags()
-{
-    const char* e = std::getenv("ADSB_AMD_ORDER_EVENT_FENCE");
-    return (e && e[0] == '1') ? hipEventDefault : hipEventDisableSystemFence;
-}
+// How the record count of a scan reaches the host: the ordering pass's last workgroup writes {count, overflow flag, launch stamp} as ONE
+// 8-byte system-scope store into page-locked host memory and the host polls the stamp; nothing but the two kernels is on the scan's
+// stream.  (Round 3 copied the two words and recorded an event on the scan's stream: 11 us of that stream per step.  A copy + event on a
+// control stream behind the pass's event was measured too: the runtime's 8-byte copy is a kernel, beside the 2.4 MS/s scan it got onto the
+// chip 0.1-0.2 ms late and the GPU idled 75 us per step -- and a stream told to wait for an event that rides on a dispatch and is re-used
+// every launch did not reliably wait.  Both forms are gone; profiles/r04_step_timeline.txt has their figures.)
 
 void free_slot(Slot& s)
 {
@@ -168,13 +142,7 @@ int ensure_slot(adsb_amd_ctx* c, Slot& s, size_t chunks, size_t cap, unsigned ma
     }
     free_slot(s);
     size_t nch = chunks ? chunks : 1;
-    if (const char* e = std::getenv("ADSB_AMD_DIAG_ALLOC_PAD_KB"))
-    { // measurements only: shift where the slot's buffers lie (profiles/r04_sweep.txt, item 0) -- the pad is never freed
-        void* pad = nullptr;
-        const size_t kb = (size_t)std::atol(e);
-        if (kb) (void)hipMalloc(&pad, kb << 10);
-    }
-    HIP_TRY(c, hipMalloc(&s.counts, 2 * nch * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&s.counts, nch * sizeof(uint32_t)));
     s.sums_words = ((nch + kOrderChunks - 1) / kOrderChunks) * kSumStride;
     s.sums_phase = 0;
     HIP_TRY(c, hipMalloc(&s.block_sums, 2 * s.sums_words * sizeof(uint32_t)));
@@ -220,9 +188,6 @@ int make_args(adsb_amd_ctx* c, const void* iq_device, size_t nbytes, size_t buff
     std::memset(a, 0, sizeof(*a));
     a->iq             = static_cast<const uint8_t*>(iq_device);
     a->buf_stride     = bb;
-#ifdef ADSB_AMD_DIAG_ALIAS // diagnostic builds: every buffer is the first one again (the scan's arithmetic without its memory traffic)
-    a->buf_stride = 0;
-#endif
     a->buf_samples    = (uint32_t)(bb / 2);
     a->nbuf           = (uint32_t)nbuf;
     a->chunks_per_buf = c->mode == ADSB_AMD_MODE_2400 ? chunks_per_buffer_2400(a->buf_samples) : chunks_per_buffer(a->buf_samples);
@@ -243,10 +208,7 @@ int make_args(adsb_amd_ctx* c, const void* iq_device, size_t nbytes, size_t buff
     if (a->group_log2)
     {
         const uint32_t round = (c->nxcd * kSubRanges) << a->group_log2;
-#ifndef ADSB_AMD_POOL_DIV
-#define ADSB_AMD_POOL_DIV 16u
-#endif
-        const uint32_t main  = (a->total_chunks - a->total_chunks / ADSB_AMD_POOL_DIV) / round * round;
+        const uint32_t main  = (a->total_chunks - a->total_chunks / 16u) / round * round;
         if ((uint64_t)main >= 4ull * scan_grid(*a)) a->main_chunks = main;
     }
     return ADSB_AMD_OK;
@@ -257,20 +219,6 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     s.args.chunk_records = s.regions;
     s.args.chunk_dir     = s.counts;
     s.args.cap           = (uint32_t)s.cap_per_chunk;
-    // Log mode (scan1090.h): the same memory cut into one log per wave instead of one region per chunk, as long as a record index fits 32
-    // bits and no scan of this context has overflowed a log (then the regions, whose hard bound of two records per position holds for
-    // any input, take over for good: wait_scan).
-    {
-        const uint64_t room = (uint64_t)s.args.total_chunks * s.cap_per_chunk;
-        const uint32_t grid = s.args.total_chunks ? scan_grid(s.args) : 1u;
-        s.args.log_cap      = (c->logs_ok && room < (1ull << 32)) ? (uint32_t)(room / grid) : 0u;
-#ifdef ADSB_AMD_LOG_SKEW // experiment: log starts that do not all fall on the same place modulo 32 KiB (a log is log_cap x 32 bytes: an odd number of 128-byte lines)
-        if (s.args.log_cap >= 64 && ((s.args.log_cap / 4) & 1u) == 0) s.args.log_cap -= 4;
-#endif
-#ifdef ADSB_AMD_LOG_CAP_MAX // experiment: a smaller footprint of the logs in the address space
-        if (s.args.log_cap > ADSB_AMD_LOG_CAP_MAX) s.args.log_cap = ADSB_AMD_LOG_CAP_MAX;
-#endif
-    }
     s.args.work_counters = s.work_d;
     s.args.block_sums    = s.block_sums + (size_t)s.sums_phase * s.sums_words;
     uint32_t* next_sums  = s.block_sums + (size_t)(s.sums_phase ^ 1) * s.sums_words;
@@ -281,9 +229,7 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     // kernels do not get onto the chip while 4096 persistent workgroups are being placed.  Round 3, a third time, with what could
     // have kept it off a CU removed: the pass rewritten without LDS (a scan's sixteen waves hold all of a CU's) and held to 64 VGPRs
     // (the scan's waves leave that many per SIMD) -- 0.263 -> 0.313 and 0.280 -> 0.333 ms per step.)
-#ifdef ADSB_AMD_STAMPS
     s.args.stamps = c->stamps_d ? c->stamps_d + (size_t)4 * kStampGroups * (c->stamp_no++ % kStampSteps) : nullptr;
-#endif
     s.seq++;
     s.events = c->timing_every != 0 && (c->submits++ % c->timing_every) == 0;
     // the two timing events ride on the kernel's dispatch (scan1090.h); an empty input launches nothing and is not timed
@@ -292,22 +238,11 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     else HIP_TRY(c, launch_scan1090(s.args, s.total_d, s.stream, s.events ? s.ev_scan0 : nullptr, s.events ? s.ev_scan1 : nullptr));
     HIP_TRY(c, launch_order1090(s.args, (s.produced & ADSB_AMD_OUT_RECORDS) ? s.dense : nullptr, (s.produced & ADSB_AMD_OUT_DECODED) ? s.decoded : nullptr,
                                 (s.produced & ADSB_AMD_OUT_PACKED) ? s.packed : nullptr, next_sums, (uint32_t)(s.sums_words / kSumStride), s.total_d, s.stream, s.args.total_chunks ? s.ev_order : nullptr,
-                                c->count_path == kCountHost ? s.total_h_dev : nullptr, s.seq));
-    if (!s.args.total_chunks) HIP_TRY(c, hipEventRecord(s.ev_order, s.stream)); // (otherwise the ordering pass's dispatch carries it)
-    if (c->count_path == kCountHost)
-    {
-        if (!s.args.total_chunks) __atomic_store_n(s.total_h, (unsigned long long)(s.seq & 0x7FFFFFFFu) << 33, __ATOMIC_RELEASE); // nothing was launched: no records
-    }
-    else if (c->count_path == kCountCtl)
-    {
-        HIP_TRY(c, hipStreamWaitEvent(c->ctl_stream, s.ev_order, 0));
-        HIP_TRY(c, hipMemcpyAsync(s.total_h, s.total_d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->ctl_stream));
-        HIP_TRY(c, hipEventRecord(s.ev_done, c->ctl_stream));
-    }
-    else
-    {
-        HIP_TRY(c, hipMemcpyAsync(s.total_h, s.total_d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
-        HIP_TRY(c, hipEventRecord(s.ev_done, s.stream));
+                                s.total_h_dev, s.seq));
+    if (!s.args.total_chunks)
+    { // nothing was launched: no records (otherwise the ordering pass's dispatch carries the event and its last workgroup stores the word)
+        HIP_TRY(c, hipEventRecord(s.ev_order, s.stream));
+        __atomic_store_n(s.total_h, (unsigned long long)(s.seq & 0x7FFFFFFFu) << 33, __ATOMIC_RELEASE);
     }
     return ADSB_AMD_OK;
 }
@@ -365,9 +300,6 @@ extern "C" int adsb_amd_create_mode(adsb_amd_ctx_t** out, int device, int mode)
     }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-    if ((e = hipStreamCreateWithFlags(&c->ctl_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-    c->count_path = count_path_from_env();
-    if (const char* e = std::getenv("ADSB_AMD_RECORD_LOGS")) c->logs_ok = e[0] == '1'; // (A/B)
 
     uint32_t tab[112];
     build_crc_table(tab);
@@ -382,23 +314,24 @@ extern "C" int adsb_amd_create_mode(adsb_amd_ctx_t** out, int device, int mode)
         if ((e = hipHostMalloc(&s.total_h, sizeof(unsigned long long), hipHostMallocMapped)) != hipSuccess) return bail("hipHostMalloc(total)", e);
         *s.total_h = 0;
         if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&s.total_h_dev), s.total_h, 0)) != hipSuccess) return bail("hipHostGetDevicePointer(total)", e);
-        // The two events around the scan kernel are read for their time stamps only, after ev_done has been waited for: no system-scope
-        // release when they are recorded (an event costs ~5 us of stream time with it, ~3 without; a fourth event per step is gone).
+        // The three events ride on dispatches and order device work / give time stamps only; what the host reads (the count word, the
+        // records) it reads after waiting for ev_order itself: no system-scope release when they are recorded (an event costs ~5 us of
+        // stream time with it, ~3 without).
         if ((e = hipEventCreateWithFlags(&s.ev_scan0, hipEventDisableSystemFence)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&s.ev_scan1, hipEventDisableSystemFence)) != hipSuccess) return bail("hipEventCreate", e);
-        if ((e = hipEventCreateWithFlags(&s.ev_order, order_event_flags())) != hipSuccess) return bail("hipEventCreate", e);
-        if ((e = hipEventCreate(&s.ev_done)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&s.ev_order, hipEventDisableSystemFence)) != hipSuccess) return bail("hipEventCreate", e);
     }
-#ifdef ADSB_AMD_STAMPS
-    if ((e = hipMalloc(&c->stamps_d, (size_t)kStampSteps * 4 * kStampGroups * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(stamps)", e);
-    if ((e = hipMemset(c->stamps_d, 0, (size_t)kStampSteps * 4 * kStampGroups * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset(stamps)", e);
-#endif
+    if constexpr (diag::kStamps)
+    {
+        if ((e = hipMalloc(&c->stamps_d, (size_t)kStampSteps * 4 * kStampGroups * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(stamps)", e);
+        if ((e = hipMemset(c->stamps_d, 0, (size_t)kStampSteps * 4 * kStampGroups * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset(stamps)", e);
+    }
     *out = c;
     return ADSB_AMD_OK;
 }
 
-#ifdef ADSB_AMD_STAMPS
-// diagnostic builds: every wave's clock values of one launch of the ring (4 x kStampGroups values: scan in, scan out, ordering pass in, out)
+#if DIAG_STAMPS
+// measurement builds: every wave's clock values of one launch of the ring (4 x kStampGroups values: scan in, scan out, ordering pass in, out)
 extern "C" int adsb_amd_debug_stamps_raw(adsb_amd_ctx_t* c, unsigned launch, unsigned long long* out)
 {
     if (!c || !out) return ADSB_AMD_EINVAL;
@@ -437,7 +370,6 @@ extern "C" void adsb_amd_destroy(adsb_amd_ctx_t* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    if (c->ctl_stream) (void)hipStreamSynchronize(c->ctl_stream);
     for (Slot& s : c->slot)
     {
         free_slot(s);
@@ -450,14 +382,13 @@ extern "C" void adsb_amd_destroy(adsb_amd_ctx_t* c)
         if (s.ev_scan0) (void)hipEventDestroy(s.ev_scan0);
         if (s.ev_scan1) (void)hipEventDestroy(s.ev_scan1);
         if (s.ev_order) (void)hipEventDestroy(s.ev_order);
-        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     }
     if (c->crc_tab) (void)hipFree(c->crc_tab);
     if (c->lut978) (void)hipFree(c->lut978);
     if (c->staging) (void)hipFree(c->staging);
+    if (c->stamps_d) (void)hipFree(c->stamps_d);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    if (c->ctl_stream) (void)hipStreamDestroy(c->ctl_stream);
     delete c;
 }
 
@@ -491,17 +422,9 @@ namespace
 // with regions eight times larger, up to the hard bound of two records per preamble position -- as long as the record arrays
 // (regions + dense + decoded) still fit in free device memory; beyond that the call fails with ADSB_AMD_ENOMEM instead of leaning on
 // hipMalloc to refuse.  The region size that worked is remembered for BOTH slots (the other one starts its next scan with it).
-// The slot's record count and overflow flag -> s.nrecords, s.overflow (see count_path_from_env).
+// The slot's record count and overflow flag -> s.nrecords, s.overflow.
 int wait_count(adsb_amd_ctx* c, Slot& s)
 {
-    if (c->count_path != kCountHost)
-    {
-        HIP_TRY(c, hipEventSynchronize(s.ev_done));
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(s.total_h);
-        s.nrecords        = w[0];
-        s.overflow        = w[1] != 0;
-        return ADSB_AMD_OK;
-    }
     // Poll the stamp.  The word is written once per launch, by one store; the pass's event is asked now and then so that a launch that
     // failed (the event completes in error, or completes without the word ever arriving) ends the wait instead of hanging it.
     const unsigned long long want = s.seq & 0x7FFFFFFFu;
@@ -551,13 +474,8 @@ int wait_scan(adsb_amd_ctx* c, Slot& s)
             if (rc) return rc;
         }
         if (!s.overflow) break;
-        if (s.args.log_cap)
-        { // a wave's log was full (input far denser than the regions were sized for): once more with a region per chunk, same memory
-            c->logs_ok = false;
-            const int rc = enqueue(c, s);
-            if (rc) return rc;
-            continue;
-        }
+        // the pass that reported the overflow is still zeroing the other sum array and the work counters: it has to be done before the repeat
+        HIP_TRY(c, hipEventSynchronize(s.ev_order));
         size_t cap = s.cap_per_chunk * 8;
         if (cap > (size_t)2 * kChunk) cap = (size_t)2 * kChunk;
         if (cap == s.cap_per_chunk) return fail(c, ADSB_AMD_EHIP, "record overflow at the maximum region size (internal error)");
@@ -581,6 +499,14 @@ int wait_scan(adsb_amd_ctx* c, Slot& s)
     return ADSB_AMD_OK;
 }
 
+// The scan kernel's and the whole submit's device time of a slot whose pass has been waited for (the scan is the first thing a submit
+// enqueues).  A scan without the two events, or events the runtime cannot read, leave the slot untimed.
+void read_timing(Slot& s)
+{
+    s.timed = s.events && hipEventElapsedTime(&s.scan_ms, s.ev_scan0, s.ev_scan1) == hipSuccess &&
+              hipEventElapsedTime(&s.total_ms, s.ev_scan0, s.ev_order) == hipSuccess;
+}
+
 // Body of fetch; the caller clears `pending` whatever the outcome, so a failed sync or copy never wedges the slot.  `what`: ADSB_AMD_OUT_* to
 // bring to the host.
 int fetch_slot(adsb_amd_ctx* c, Slot& s, unsigned what)
@@ -593,14 +519,14 @@ int fetch_slot(adsb_amd_ctx* c, Slot& s, unsigned what)
     }
     int rc = ensure_host(c, s, s.nrecords);
     if (rc) return rc;
-    static const bool diag_no_copy = std::getenv("ADSB_AMD_DIAG_NO_COPY") != nullptr; // measurements only: the scan without the record copy beside it
-    if (s.nrecords && !diag_no_copy)
+    // The count comes from the pass's LAST workgroup: others may still be moving records, zeroing the slot's other sum array or its work
+    // counters.  So the host waits for the pass's event before anything else happens to the slot -- the copy below, or (no records) the
+    // slot's next submit, which may come on another stream.  The stamp is normally there only just before the pass ends: microseconds.
+    // (A stream-side wait instead -- hipStreamWaitEvent on the copy stream -- was not reliable with an event that rides on a dispatch
+    // and is re-used every launch: stale records were seen with three slots in flight.)
+    HIP_TRY(c, hipEventSynchronize(s.ev_order));
+    if (s.nrecords)
     {
-        // The count comes from the pass's last workgroup: others may still be moving records.  The pass's event rides on its dispatch, and a
-        // stream that is told to wait for such an event right away can find the event still standing for its previous use (seen with the
-        // scan's stop event: a pass on another stream started before its scan had ended); the HOST, which has seen this launch's stamp, cannot:
-        // it waits for the event here (microseconds), then the copy needs no wait of its own.
-        if (c->count_path == kCountHost) HIP_TRY(c, hipEventSynchronize(s.ev_order));
         if (what & ADSB_AMD_OUT_RECORDS)
             HIP_TRY(c, hipMemcpyAsync(s.host, s.dense, s.nrecords * sizeof(adsb_amd_record_t), hipMemcpyDeviceToHost, c->copy_stream));
         if (what & ADSB_AMD_OUT_DECODED)
@@ -610,12 +536,7 @@ int fetch_slot(adsb_amd_ctx* c, Slot& s, unsigned what)
         HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     }
     s.dec_valid = (what & ADSB_AMD_OUT_DECODED) != 0;
-    s.timed     = s.events;
-    if (s.events)
-    {
-        (void)hipEventElapsedTime(&s.scan_ms, s.ev_scan0, s.ev_scan1);
-        (void)hipEventElapsedTime(&s.total_ms, s.ev_scan0, c->count_path == kCountHost ? s.ev_order : s.ev_done); // the scan is the first thing a submit enqueues
-    }
+    read_timing(s);
     return ADSB_AMD_OK;
 }
 } // namespace
@@ -716,22 +637,17 @@ int fetch_device_impl(adsb_amd_ctx_t* c, int slot, void* dst_device, size_t cap,
         if (!(s.produced & (packed ? ADSB_AMD_OUT_PACKED : ADSB_AMD_OUT_RECORDS)))
             return fail(c, ADSB_AMD_ESTATE, "this slot's scan did not produce the array asked for (adsb_amd_set_outputs)");
         if (s.nrecords > cap) return fail(c, ADSB_AMD_ENOSPC, "destination too small");
+        HIP_TRY(c, hipEventSynchronize(s.ev_order)); // (see fetch_slot: always, records or not)
         if (s.nrecords)
         {
             hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->copy_stream;
-            if (c->count_path == kCountHost) HIP_TRY(c, hipEventSynchronize(s.ev_order)); // (see fetch_slot)
             // hipMemcpyDefault: the destination may be device memory or page-locked / registered host memory (shard.NodeGather)
             static_assert(sizeof(adsb_amd_record_t) == sizeof(adsb_amd_packed_t), "one size for both forms");
             HIP_TRY(c, hipMemcpyAsync(dst_device, packed ? static_cast<const void*>(s.packed) : static_cast<const void*>(s.dense),
                                       s.nrecords * sizeof(adsb_amd_record_t), hipMemcpyDefault, st));
             if (!hip_stream) HIP_TRY(c, hipStreamSynchronize(st));
         }
-        s.timed = s.events;
-        if (s.events)
-        {
-            (void)hipEventElapsedTime(&s.scan_ms, s.ev_scan0, s.ev_scan1);
-            (void)hipEventElapsedTime(&s.total_ms, s.ev_scan0, c->count_path == kCountHost ? s.ev_order : s.ev_done); // the scan is the first thing a submit enqueues
-        }
+        read_timing(s);
         return ADSB_AMD_OK;
     };
     const int rc = body();

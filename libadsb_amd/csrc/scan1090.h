@@ -14,13 +14,8 @@ namespace adsb_amd
 // of one reference buffer out of an LDS-staged window of kChunk + kHalo samples.
 constexpr int kLanes      = 64;
 constexpr int kRowSamples = 512; // one 16-byte load per lane = 8 IQ samples per lane = 512 per wavefront
-#ifndef ADSB_AMD_ROWS
-#define ADSB_AMD_ROWS 8
-#endif
-#ifndef ADSB_AMD_WAVES_PER_CU
-#define ADSB_AMD_WAVES_PER_CU 16
-#endif
-constexpr int kRows       = ADSB_AMD_ROWS; // 1 KiB load rows per chunk (experiments: 6 rows = 3072 positions let a CU hold 20 waves, profiles/r04_sweep.txt)
+constexpr int kRows       = 8;   // 1 KiB load rows per chunk (6 rows = 3072 positions, 20 waves a CU: measured, not kept, profiles/r04_sweep.txt)
+constexpr int kWavesPerCu = 16;  // single-wave workgroups of the persistent scan kernels a CU holds (LDS-limited)
 constexpr int kChunk      = kRows * kRowSamples; // 4096 positions
 constexpr int kHalo       = 256;                 // >= 240 samples read past the last position, half a row
 constexpr int kFrameSpan  = 240;                 // (8 + 112) * 2 samples: reference loop bound (ADSB1090.cpp:772)
@@ -51,35 +46,27 @@ struct ScanArgs
     uint32_t           main_chunks;  // chunks [0, main_chunks) are dealt out by the XCDs' own counters (scan_common.hip.h, WorkRange), the rest -- the pool,
                                      // about a sixteenth, none for small inputs -- by counters that waves of every XCD draw from once their own is dry
     const uint32_t*    crc_tab;      // 112 entries (ModesChecksumTable semantics)
-    adsb_amd_record_t* chunk_records; // total_chunks * cap raw records: one region of `cap` per chunk, or (log_cap != 0) one log of log_cap per wave
-    uint32_t*          chunk_dir;     // two words per chunk: index of its first raw record in chunk_records (log mode), records kept (<= room)
+    adsb_amd_record_t* chunk_records; // total_chunks * cap raw records: one region of `cap` per chunk.  (Per-wave logs instead of per-chunk regions,
+                                      // so that the ordering pass reads dense memory, were measured in round 4: the scan 3 % slower, the pass no
+                                      // faster once it had a lane per record -- profiles/r04_sweep.txt; not kept.)
+    uint32_t*          chunk_dir;     // one word per chunk: records kept (<= cap)
     uint32_t           cap;           // records per chunk region
-    uint32_t           log_cap;       // 0: a chunk's records go to its own region (chunk * cap).  Otherwise every wave appends the records of
-                                      // all its chunks to ONE log of log_cap records (wave w: [w * log_cap, (w + 1) * log_cap)): what the ordering
-                                      // pass reads is then dense (the regions are 64 used bytes per KiB, which costs the pass two thirds of its time)
     uint32_t*          work_counters; // kSubRanges per XCD, counter c at [32 * c] (own cache line each), zero when the scan starts; the ordering pass zeroes them again
     uint32_t           nxcd;          // XCDs of the device (hipDeviceAttributeNumberOfXccs; 8 on MI355X), <= kMaxXcd
     uint32_t           ncu;           // compute units of the device (256 on MI355X)
-#ifdef ADSB_AMD_STAMPS
-    unsigned long long* stamps;       // diagnostic builds (tools/stamps.py): {scan first wave in, scan last wave out, ordering pass in, out} of this launch, 100 MHz clock
-#endif
+    unsigned long long* stamps;       // NULL in the product build; measurement builds (diag.hip.h, tools/stamps.py): {scan wave in, scan wave out,
+                                      // ordering pass in, out} of this launch per wave, 100 MHz clock
     uint32_t*          block_sums;    // one padded entry (kSumStride words) per kOrderChunks chunks, zero when the scan starts: [0] += records of a
                                       // finished chunk (clamped to cap), [1] |= 1 when a chunk found more than cap
 };
 constexpr uint32_t kOrderChunks = 256; // chunks per entry of block_sums = per workgroup of the ordering pass
-#ifndef ADSB_AMD_SUM_STRIDE
-#define ADSB_AMD_SUM_STRIDE 32
-#endif
-constexpr uint32_t kSumStride   = ADSB_AMD_SUM_STRIDE;  // words between entries: an entry per 128-byte line (one atomic per chunk lands on it)
+constexpr uint32_t kSumStride   = 32; // words between entries: an entry per 128-byte line (one atomic per chunk lands on it)
 
 constexpr uint32_t kSubRanges   = 4;  // work counters per XCD
 constexpr uint32_t kMaxXcd      = 16;
 constexpr uint32_t kWorkCounters = 2 * kSubRanges * kMaxXcd; // the XCDs' own, then as many for the pool (from kPoolBase)
 constexpr uint32_t kPoolBase     = kSubRanges * kMaxXcd;
-#ifndef ADSB_AMD_COUNTER_STRIDE
-#define ADSB_AMD_COUNTER_STRIDE 32
-#endif
-constexpr uint32_t kCounterStride = ADSB_AMD_COUNTER_STRIDE; // words between work counters
+constexpr uint32_t kCounterStride = 32; // words between work counters (a 128-byte line each)
 
 inline uint32_t chunks_per_buffer(uint32_t buf_samples)
 {
@@ -93,20 +80,19 @@ inline uint32_t chunks_per_buffer(uint32_t buf_samples)
 inline uint32_t scan_grid(const ScanArgs& a)
 {
     const uint32_t unit = a.nxcd * kSubRanges; // every (XCD, sub-range) gets the same number of waves
-    uint32_t       grid = (a.ncu * (uint32_t)ADSB_AMD_WAVES_PER_CU / unit) * unit;
+    uint32_t       grid = (a.ncu * (uint32_t)kWavesPerCu / unit) * unit;
     if (grid == 0) grid = unit;
     if (grid > a.total_chunks) grid = ((a.total_chunks + unit - 1u) / unit) * unit;
     return grid;
 }
 
-// Demodulation kernel (fills the raw record regions / logs and the chunk directory; zeroes `total_and_overflow`).
+// Demodulation kernel (fills the raw record regions and the chunk directory; zeroes `total_and_overflow`).
 // `start` / `stop` (either may be NULL): events that take the kernel's own start and end times -- they ride on the dispatch
 // (hipExtLaunchKernelGGL), where two hipEventRecord calls around the launch are packets of their own on the stream, 3-5 us each.
 hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // Ordering pass: the sorted gather into `dense` (+ field decode).  `total_and_overflow` is a device uint32_t[2]: {number of
 // records in dense, overflow flag}.  a.block_sums holds what the scan accumulated; `next_block_sums` (`next_entries` padded entries, the
-// slot's whole second array) is zeroed for the next scan of this slot, and so are the work counters.  (Letting the pass write the two words into page-locked host memory
-// itself, instead of the 8-byte copy that follows it in the stream, was measured 40 us per step slower.)
+// slot's whole second array) is zeroed for the next scan of this slot, and so are the work counters.
 // dense / decoded / packed: the arrays to produce (any may be NULL)
 // `done` (may be NULL): event that takes the pass's end (riding on its dispatch like the scan's two)
 hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, adsb_amd_decoded_t* decoded, adsb_amd_packed_t* packed, uint32_t* next_block_sums,

@@ -244,9 +244,6 @@ __device__ __forceinline__ int demod_strong_frame(const uint16_t* tile, uint32_t
     const bool     strong  = is_long ? (strongA == ~0ull && (strongB & kMask48) == kMask48) : ((strongA & kMask56) == kMask56);
     if (!strong || !(is17 || df_is_ap(df)))
     {
-#if defined(ADSB_AMD_DIAG) && ADSB_AMD_DIAG >= 2
-        return 1;
-#endif
         const u16x2    lim = {1023, 1023};
         const uint32_t trm = as_u32(__builtin_elementwise_min(as_pk(__builtin_amdgcn_perm(0u, mx, fc.sel_sums)), lim));
         const uint32_t sum = wave_sum(trm);
@@ -445,20 +442,10 @@ __device__ __forceinline__ void queue_survivors(uint64_t surv, uint32_t first, i
     }
 }
 
-#ifdef ADSB_AMD_SPLIT_PREFETCH // experiment (profiles/r04_sweep.txt): the next window in two bursts, rows 0-3 behind the image build, the rest behind stage 1
-__device__ __forceinline__ uint4 load_row_at(const ChunkGeom& g, int k, int lane)
-{
-    return *reinterpret_cast<const uint4*>(g.buf + 2ull * g.g0 + (uint32_t)(k * kRowSamples * 2) + 16u * (uint32_t)lane);
-}
-#endif
-#ifndef ADSB_AMD_MIN_WAVES
-#define ADSB_AMD_MIN_WAVES 4
-#endif
-// Profiling builds only (tools/parts.sh): 1 = window load + s, 2 = + stage 1, 3 = + survivor queue and stage 2, 4 = everything.
-#ifndef ADSB_AMD_PARTS
-#define ADSB_AMD_PARTS 4
-#endif
-__global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow)
+// Measurement builds (diag.hip.h, tools/parts.sh) compile the later parts out: 0 = the loads alone, 1 = + window -> s, 2 = + stage 1,
+// 3 = + survivor queue and stage 2, more = everything (the product).
+constexpr int kParts = diag::kParts;
+__global__ __launch_bounds__(64, 4) void scan1090_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow)
 {
     // the interleaved image of s (scan1090.h), the slot of the sample in front of the chunk, then the survivor queue.  The queue
     // doubles as the landing zone of the fast demodulation path's reads beyond a window (lanes 48..63 have no second bit; what
@@ -468,9 +455,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
     uint16_t* const                                  queue = reinterpret_cast<uint16_t*>(&tile32[kTileDwords]);
 
     const int        lane = threadIdx.x;
-#ifdef ADSB_AMD_STAMPS
     stamp(a.stamps, 0);
-#endif
     const LaneTables lt   = load_lane_tables(a.crc_tab, lane);
     const FastConsts fc   = fast_consts(lane);
     const uint32_t   tile_addr = lds_address(tile32), queue_addr = lds_address(queue);
@@ -487,23 +472,21 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
     ChunkGeom g     = chunk_geom_of(a, chunk, kFrameSpan);
     RawWindow raw;
     load_window<kHalo, false, true>(g, lane, raw);
-    uint32_t logged = 0; // records in this wave's log (ScanArgs::log_cap)
 
     for (;;)
     {
         // ---------------- s = (I-127)^2 + (Q-127)^2 for the window, parked in LDS: row j (lower half) beside row j + 4 (upper half)
         __builtin_amdgcn_s_setprio(0);
         wave_lds_fence(); // readers of the previous chunk are done
-#if ADSB_AMD_PARTS == 0
-        { // profiling build: the loads and nothing else (what does this access pattern alone cost?)
+        if constexpr (kParts == 0)
+        { // measurement build: the loads and nothing else (what does this access pattern alone cost?)
             uint32_t x = raw.cont_hi.x ^ raw.cont_hi.y;
 #pragma unroll
             for (int j = 0; j < kRows; j++) x ^= raw.row[j].x ^ raw.row[j].y ^ raw.row[j].z ^ raw.row[j].w;
             if (x == 0x12345679u) total_overflow[1] = x; // never true for real input, keeps the loads alive
         }
-#else
 #pragma unroll
-        for (int j = 0; j < kRows / 2; j++)
+        for (int j = 0; j < (kParts >= 1 ? kRows / 2 : 0); j++)
         {
             uint32_t    t[8];
             const uint4 x = raw.row[j], y = raw.row[j + kRows / 2];
@@ -515,6 +498,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
             dst[0]     = make_uint4(t[0], t[1], t[2], t[3]);
             dst[1]     = make_uint4(t[4], t[5], t[6], t[7]);
         }
+        if constexpr (kParts >= 1)
         { // The continuation, 256 dwords, four per lane: the low halves repeat the start of the upper half, which the first pass above has
           // just written into the high halves of dwords 0 .. 255 -- read back from there (one 16-byte read per lane) --, the high halves are
           // the halo, squared here two samples of the same row per register.  16 vector instructions; as a fifth pass of the loop above
@@ -527,7 +511,6 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
                 make_uint4(__builtin_amdgcn_perm(h01, lo.x, 0x05040302u), __builtin_amdgcn_perm(h01, lo.y, 0x07060302u),
                            __builtin_amdgcn_perm(h23, lo.z, 0x05040302u), __builtin_amdgcn_perm(h23, lo.w, 0x07060302u));
         }
-#endif
 
         // ---------------- prefetch: the next chunk's loads fly while this chunk is processed
         const ChunkGeom cur = g;
@@ -540,21 +523,9 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         publish(a, pend, lane);
         uint32_t ticket = 0;
         if (next != kNoChunk) ticket = grab_issue(a, wr, lane);
-#ifdef ADSB_AMD_SPLIT_PREFETCH
-        bool split = false;
-#endif
         if (next != kNoChunk)
         {
             g = chunk_geom_of(a, next, kFrameSpan);
-#ifdef ADSB_AMD_SPLIT_PREFETCH
-            split = g.g0 + (uint32_t)(kChunk + kHalo) <= g.n;
-            if (split)
-            {
-#pragma unroll
-                for (int k = 0; k < kRows / 2; k++) raw.row[k] = load_row_at(g, k, lane);
-            }
-            else
-#endif
             load_window<kHalo, false, true>(g, lane, raw);
             // (Touching the chunk after that one into the caches -- one dword per 64 bytes, two chunks ahead, so that the memory system has
             // requests while the wave computes -- was tried: the kernel went from 0.212 to 0.32 ms; profiles/r03_sweep.txt.  So was issuing
@@ -571,7 +542,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         // and max(s_a, s_a+2) is one shared array (used at a = 1, 4 and 6).
         uint32_t surv32[2] = {0u, 0u};
 #pragma unroll
-        for (int b = 0; b < (ADSB_AMD_PARTS >= 2 ? kHalfChunk / 512 : 0); b++)
+        for (int b = 0; b < (kParts >= 2 ? kHalfChunk / 512 : 0); b++)
         {
             uint32_t        T[17];
             const uint32_t* p  = &tile32[b * 512 + 8 * lane];
@@ -616,15 +587,6 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         }
         // bit n of surv: the half at index 1024 (n >> 4) + 16 lane + (n & 15) of the image (tile_index of its position)
         uint64_t surv = (uint64_t)surv32[0] | ((uint64_t)surv32[1] << 32);
-#ifdef ADSB_AMD_SPLIT_PREFETCH
-        if (split)
-        {
-#pragma unroll
-            for (int k = kRows / 2; k < kRows; k++) raw.row[k] = load_row_at(g, k, lane);
-            raw.cont_hi = *reinterpret_cast<const uint2*>(g.buf + 2ull * g.g0 + 2u * (uint32_t)kChunk + 8u * (uint32_t)lane);
-            raw.front   = 0x7F7Fu;
-        }
-#endif
         // The rest of the chunk is short dependent chains (scalar work, LDS round trips, a few vector operations at a time); the other
         // waves of the SIMD are mostly in the vector-dense image and stage-1 phases.  With raised priority these chains issue as soon as
         // they are ready instead of queueing behind that work, the wave is back in a dense phase sooner, and the vector unit idles less:
@@ -646,9 +608,9 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
         const uint32_t mine = (uint32_t)__builtin_popcountll(surv);
         const uint32_t incl = wave_incl_scan_add(mine);
         const uint32_t n1   = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        Emit           e = begin_chunk(a, me, logged);
-        if (ADSB_AMD_PARTS < 3) e.count = (n1 == 0xFFFFFFFFu) ? 1u : 0u; // part builds: keep what was computed alive, emit nothing
-        for (uint32_t base = 0; ADSB_AMD_PARTS >= 3 && base < n1; base += (uint32_t)kQueueCap)
+        Emit           e = begin_chunk(a, me);
+        if (kParts < 3) e.count = (n1 == 0xFFFFFFFFu) ? 1u : 0u; // part builds: keep what was computed alive, emit nothing
+        for (uint32_t base = 0; kParts >= 3 && base < n1; base += (uint32_t)kQueueCap)
         {
             if (n1 <= (uint32_t)kQueueCap) queue_survivors<false>(surv, incl - mine, lane, queue_addr, 0u);
             else queue_survivors<true>(surv, incl - mine, lane, queue_addr, base);
@@ -704,9 +666,9 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
                     }
                 }
                 uint64_t mk = ballot(ok);
-                if (ADSB_AMD_PARTS < 4) e.count += (mk == 0x123456789ull) ? 1u : 0u;
+                if (kParts < 4) e.count += (mk == 0x123456789ull) ? 1u : 0u;
                 // demodulate the candidates, one at a time, whole wave each (the order inside a chunk is the ordering pass's business)
-                while (ADSB_AMD_PARTS >= 4 && mk)
+                while (kParts >= 4 && mk)
                 {
                     const int      src = __builtin_ctzll(mk);
                     mk &= mk - 1ull;
@@ -718,16 +680,12 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
                     w.am1 = a0 == 0 ? (uint32_t)kFrontSlot16 : (a0 == 1u ? (uint32_t)(2 * (kHalfChunk - 1)) : a0 - 2u);
                     const uint8_t* front = cur.buf + 2ull * (cur.g0 - 1u); // only dereferenced for position 0 of a chunk that is not the buffer's first
                     const int      todo  = demod_strong_frame(tile, tile_addr, lane, lt, fc, e, w, cur.g0 + pos, front);
-#if !defined(ADSB_AMD_DIAG) || ADSB_AMD_DIAG < 1 // diagnostic builds (wrong results): 1 = no general demodulator, 2 = nor the noise bound
                     if (todo) demod_candidate(tile, lane, lt, e, w, cur.g0 + pos, todo == 2, front);
-#else
-                    if (todo == 77) e.count++;
-#endif
                 }
             }
             wave_lds_fence();
         }
-        pend = finish_chunk(me, e, &logged);
+        pend = finish_chunk(me, e);
 
         if (next == kNoChunk) break;
         chunk = next;
@@ -735,9 +693,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_MIN_WAVES) void scan1090_kernel(ScanAr
     }
     publish(a, pend, lane);
     flush_records();
-#ifdef ADSB_AMD_STAMPS
     stamp(a.stamps, 1);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -798,10 +754,7 @@ __device__ __forceinline__ FieldsDev decode_fields_dev(uint32_t B0, uint32_t B1,
 // records into the dense arrays sorted by (offset, pass).
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kOrderBlock   = 256;  // chunks per workgroup of the ordering pass
-#ifndef ADSB_AMD_ORDER_THREADS
-#define ADSB_AMD_ORDER_THREADS 640
-#endif
-constexpr uint32_t kOrderThreads = ADSB_AMD_ORDER_THREADS; // its threads = records it moves per trip (a block of a quiet band holds ~550); two workgroups per CU
+constexpr uint32_t kOrderThreads = 640; // its threads = records it moves per trip (a block of a quiet band holds ~550); two workgroups per CU
 static_assert(kOrderThreads % 64 == 0 && kOrderThreads >= kOrderBlock && kOrderThreads <= 1024, "whole waves, at least the chunk threads");
 
 // Round 4.  Until then a thread walked its chunk's records one after the other -- load the record, count the chunk's smaller keys, decode,
@@ -811,7 +764,7 @@ static_assert(kOrderThreads % 64 == 0 && kOrderThreads >= kOrderBlock && kOrderT
 // the same breath, the keys of the chunk's other records (four at a time), and the whole block is done after one round trip.
 __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb_amd_record_t* __restrict__ chunk_records,
                                                             const uint32_t* __restrict__ chunk_dir, const uint32_t* __restrict__ block_sums,
-                                                            uint32_t nchunks, uint32_t nblocks, uint32_t cap, uint32_t log_cap, uint32_t chunks_per_buf,
+                                                            uint32_t nchunks, uint32_t nblocks, uint32_t cap, uint32_t chunks_per_buf,
                                                             adsb_amd_record_t* __restrict__ dense, adsb_amd_decoded_t* __restrict__ decoded,
                                                             adsb_amd_packed_t* __restrict__ packed, uint32_t* __restrict__ total_overflow,
                                                             uint32_t* __restrict__ next_block_sums,
@@ -827,7 +780,6 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
     } stamp_on_exit{stamps};
     __shared__ uint32_t before_w[kWaves], count_w[kOrderBlock / 64];
     __shared__ uint32_t cstart[kOrderBlock + 1]; // first record of each chunk among the block's records, and their total
-    __shared__ uint32_t csrc[kOrderBlock];       // log mode: index of the chunk's first raw record
     __shared__ uint8_t  owner[kOrderThreads];    // chunk (within the block) of record `trip base + t`
     __shared__ uint8_t  ais[64];                 // the identification message's character set (decode_fields_dev)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -846,8 +798,7 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
     if (host_word && blockIdx.x == nblocks - 1)
         for (uint32_t b = tid; b < nblocks; b += kOrderThreads) any_over = any_over || block_sums[b * kSumStride + 1] != 0;
     const uint32_t c  = blockIdx.x * kOrderBlock + tid;
-    const uint2    de = (tid < kOrderBlock && c < nchunks) ? *reinterpret_cast<const uint2*>(chunk_dir + 2ull * c) : make_uint2(0u, 0u); // {first raw record (log mode), records kept}
-    const uint32_t n  = de.y;
+    const uint32_t n  = (tid < kOrderBlock && c < nchunks) ? chunk_dir[c] : 0u; // records kept
     before            = wave_incl_scan_add(before);
     if (lane == 63) before_w[wave] = before;
     uint32_t incl = 0;
@@ -869,11 +820,7 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
         tot += t;
     }
     const uint32_t excl = incl - n + mine;
-    if (tid < kOrderBlock)
-    {
-        cstart[tid] = excl;
-        csrc[tid]   = de.x;
-    }
+    if (tid < kOrderBlock) cstart[tid] = excl;
     if (tid == 0) cstart[kOrderBlock] = tot;
     if (blockIdx.x == nblocks - 1 && tid == 0) total_overflow[0] = base + tot;
     if (host_word && blockIdx.x == nblocks - 1)
@@ -883,9 +830,7 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
             __hip_atomic_store(host_word, (unsigned long long)(base + tot) | ((unsigned long long)(((stamp_no & 0x7FFFFFFFu) << 1) | (over ? 1u : 0u)) << 32),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-#if defined(ADSB_AMD_ORDER_PARTS) && ADSB_AMD_ORDER_PARTS == 1 // profiling builds (wrong results): 1 = the prefix only, 2 = + fetch and store (no ranks, no decode), 3 = + ranks
-    return;
-#endif
+    if constexpr (diag::kOrderParts == 1) return; // measurement builds (no records): 1 = the prefix only, 2 = + fetch and store, 3 = + ranks
 
     for (uint32_t trip = 0; trip < tot; trip += kOrderThreads)
     {
@@ -897,15 +842,14 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
         if (r >= tot) continue;
         const uint32_t cc = owner[tid], first = cstart[cc], nn = cstart[cc + 1] - first, i = r - first;
         const uint32_t ch = blockIdx.x * kOrderBlock + cc; // the chunk
-        const uint4*   src = reinterpret_cast<const uint4*>(chunk_records + (log_cap ? (uint64_t)csrc[cc] : (uint64_t)ch * cap));
+        const uint4*   src = reinterpret_cast<const uint4*>(chunk_records + (uint64_t)ch * cap);
         const uint4    lo  = src[2 * i];
         uint4          hi  = src[2 * i + 1];
         // rank among the chunk's records by (offset, pass): their keys four at a time (a chunk seldom has more)
         const uint32_t key = (lo.x << 1) | ((lo.y >> 16) & 1u);
         uint32_t       rank = 0;
-#if defined(ADSB_AMD_ORDER_PARTS) && ADSB_AMD_ORDER_PARTS == 2
-        rank = i;
-#else
+        if constexpr (diag::kOrderParts == 2) rank = i;
+        else
         for (uint32_t k0 = 0; k0 < nn; k0 += 4)
         {
             uint2 q[4];
@@ -914,7 +858,6 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) rank += (((q[k].x << 1) | ((q[k].y >> 16) & 1u)) < key) ? 1u : 0u;
         }
-#endif
         const uint32_t buffer = ch / chunks_per_buf;
         const size_t   out    = (size_t)base + first + rank;
         // raw -> adsb_amd_record_t: apply the 1-bit repair, order the bytes, pull the address out
@@ -944,12 +887,9 @@ __global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb
             o[1]     = make_uint4(df | (flags << 8) | (m0 << 16), (m0 >> 16) | (m1 << 16), (m1 >> 16) | (m2 << 16), (m2 >> 16) | (m3 << 16));
         }
         // the stateless half of DecodeModesMessage, so that the host's sequential pass decodes nothing
-#if defined(ADSB_AMD_ORDER_PARTS) && ADSB_AMD_ORDER_PARTS <= 3
         FieldsDev d{};
-        d.a = B1 ^ key;
-#else
-        const FieldsDev d = decode_fields_dev(B0, B1, B2, df, ais);
-#endif
+        if constexpr (diag::kOrderParts <= 3) d.a = B1 ^ key;
+        else d = decode_fields_dev(B0, B1, B2, df, ais);
         if (decoded) *reinterpret_cast<uint4*>(decoded + out) = make_uint4(d.head, d.altitude, d.a, d.b);
         if (packed)
         { // the record's first sixteen bytes, then df, flags, kind, odd and the decoded values (adsb_amd_packed_t)
@@ -1027,18 +967,14 @@ hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, adsb_am
     if (a.total_chunks == 0) return hipSuccess;
     static_assert(kOrderBlock == kOrderChunks, "one block-sum entry per workgroup of the ordering pass");
     const uint32_t nblocks = (a.total_chunks + kOrderBlock - 1u) / kOrderBlock;
-#ifdef ADSB_AMD_STAMPS
     unsigned long long* const stamps = a.stamps;
-#else
-    unsigned long long* const stamps = nullptr;
-#endif
     if (done)
         hipExtLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderThreads), 0, stream, nullptr, done, 0, a.chunk_records, a.chunk_dir, a.block_sums,
-                       a.total_chunks, nblocks, a.cap, a.log_cap, a.chunks_per_buf, dense, decoded, packed, total_and_overflow, next_block_sums, next_entries, a.work_counters,
+                       a.total_chunks, nblocks, a.cap, a.chunks_per_buf, dense, decoded, packed, total_and_overflow, next_block_sums, next_entries, a.work_counters,
                        stamps, host_word, stamp);
     else
         hipLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderThreads), 0, stream, a.chunk_records, a.chunk_dir, a.block_sums,
-                       a.total_chunks, nblocks, a.cap, a.log_cap, a.chunks_per_buf, dense, decoded, packed, total_and_overflow, next_block_sums, next_entries, a.work_counters,
+                       a.total_chunks, nblocks, a.cap, a.chunks_per_buf, dense, decoded, packed, total_and_overflow, next_block_sums, next_entries, a.work_counters,
                        stamps, host_word, stamp);
     return hipGetLastError();
 }

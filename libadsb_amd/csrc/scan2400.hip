@@ -224,9 +224,7 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     uint16_t* const                                  img16 = reinterpret_cast<uint16_t*>(img);
 
     const int        lane = threadIdx.x;
-#ifdef ADSB_AMD_STAMPS
     stamp(a.stamps, 0);
-#endif
     const LaneTables lt   = load_lane_tables(a.crc_tab, lane);
     // preamble weights of this lane (see the candidate loop)
     const int tl = lane & 15, rw = lane >> 4;
@@ -243,7 +241,6 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     ChunkGeom g     = chunk_geom_of(a, chunk, kSpan24);
     RawWindow raw;
     load_window<kHalo24>(g, lane, raw);
-    uint32_t logged = 0; // records in this wave's log (ScanArgs::log_cap)
     Pending  pend{};     // the previous chunk's directory entry and sums, not yet written (scan_common.hip.h)
 
     for (;;)
@@ -344,21 +341,20 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     }
 
     // ---------------- candidates -> queue -> demodulation, kQueue24 per pass
-#if defined(ADSB_AMD_PARTS24) && ADSB_AMD_PARTS24 == 1
-    {
-        Emit e  = begin_chunk(a, me, logged);
+    if constexpr (diag::kParts == 1)
+    { // measurement build: image + gate only
+        Emit e  = begin_chunk(a, me);
         e.count = (surv == 0x123456789ull) ? 1 : 0; // keeps the gate alive
-        pend    = finish_chunk(me, e, &logged);
+        pend    = finish_chunk(me, e);
+        if (next == kNoChunk) break;
+        chunk = next;
+        next  = take_next(a, wr, ticket, lane);
+        continue;
     }
-    if (next == kNoChunk) break;
-    chunk = next;
-    next  = take_next(a, wr, ticket, lane);
-    continue;
-#endif
     const uint32_t mine = (uint32_t)__builtin_popcountll(surv);
     const uint32_t incl = wave_incl_scan_add(mine);
     const uint32_t n1   = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    Emit           e = begin_chunk(a, me, logged);
+    Emit           e = begin_chunk(a, me);
     // A pass takes whole lanes (a lane's survivors of one 8-position group are consecutive queue entries in ascending position, so
     // a run never straddles two passes) until kQueue24 entries are full.
     const uint32_t excl = incl - mine;
@@ -443,9 +439,8 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
             nw += (uint32_t)__builtin_popcountll(wins);
         }
         wave_lds_fence();
-#if defined(ADSB_AMD_PARTS24) && ADSB_AMD_PARTS24 == 2
-        if (nw != 0x12345678u) nw = 0;
-#endif
+        if constexpr (diag::kParts == 2)
+            if (nw != 0x12345678u) nw = 0; // measurement build: + queue, scores and run rule
         // ---- the candidates, one at a time with the whole wave
         for (uint32_t w = 0; w < nw; w++)
         {
@@ -458,16 +453,14 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
             // (Looking at the five DF bits first and slicing the rest only for a DF that can be accepted saved 28 vector instructions per chunk
             // in the round-2 form and cost as much in LDS round trips: dropped.)
             if (slice_and_emit(img16, a0, lane, lt, e, g0 + pos, phi_star, amp)) continue;
-#if defined(ADSB_AMD_PARTS24) && ADSB_AMD_PARTS24 == 3
-            continue;
-#endif
+            if constexpr (diag::kParts == 3) continue; // measurement build: + the first slice of the candidates
             if (phi_star + 1 <= 4 && slice_and_emit(img16, a0, lane, lt, e, g0 + pos, phi_star + 1, amp)) continue;
             if (phi_star - 1 >= 0) (void)slice_and_emit(img16, a0, lane, lt, e, g0 + pos, phi_star - 1, amp);
         }
         wave_lds_fence();
         base = next_base;
     }
-    pend = finish_chunk(me, e, &logged);
+    pend = finish_chunk(me, e);
 
     if (next == kNoChunk) break;
     chunk = next;
@@ -475,9 +468,7 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     }
     publish(a, pend, lane);
     flush_records();
-#ifdef ADSB_AMD_STAMPS
     stamp(a.stamps, 1);
-#endif
 }
 
 } // namespace

@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "diag.hip.h"
 #include "scan1090.h"
 
 namespace adsb_amd
@@ -232,7 +233,6 @@ struct Emit
     uint4*   base;  // where this chunk's records go, one raw record = 2 x uint4
     uint32_t cap;   // room there
     uint32_t count; // wave-uniform
-    uint32_t start; // index of the first of them in ScanArgs::chunk_records (log mode)
 };
 
 // A raw record is what the wave has in scalar registers anyway; turning it into the public adsb_amd_record_t (byte
@@ -253,16 +253,6 @@ __device__ __forceinline__ void emit_raw(Emit& e, int lane, uint32_t offset, uin
         auto           sc = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
         const u32x4_s  lo = {sc(offset), sc(df | (nbits << 8) | (flags << 16) | ((uint32_t)(errorbit + 1) << 24)), sc(syn), sc(extra16)};
         const u32x4_s  hi = {sc((uint32_t)ba), sc((uint32_t)(ba >> 32)), sc((uint32_t)bb), sc((uint32_t)(bb >> 32))};
-#ifdef ADSB_AMD_EMIT_VECTOR // experiment (profiles/r04_sweep.txt): the record through lane 0's vector registers, no wait behind the stores
-        if (lane == 0)
-        {
-            uint4* const q = e.base + 2 * e.count;
-            q[0]           = make_uint4(lo.x, lo.y, lo.z, lo.w);
-            q[1]           = make_uint4(hi.x, hi.y, hi.z, hi.w);
-        }
-        e.count++;
-        return;
-#endif
         const uint64_t p  = reinterpret_cast<uint64_t>(e.base + 2 * e.count);
         // The wait is needed: a scalar store has NOT read its data registers when it issues (tools/isa_probe.hip overwrites them right
         // after the store and finds the new values in memory), and the compiler, which cannot see into the block, reuses them freely.
@@ -280,18 +270,17 @@ __device__ __forceinline__ void flush_records() { asm volatile("s_dcache_wb" :::
 __device__ __forceinline__ bool df_is_long(uint32_t df) { return df == 16 || df == 17 || df == 19 || df == 20 || df == 21; }
 __device__ __forceinline__ bool df_is_ap(uint32_t df) { return df == 0 || df == 4 || df == 5 || df == 16 || df == 20 || df == 21 || df == 24; }
 
-// Diagnostic builds only (-DADSB_AMD_STAMPS, tools/stamps.py): when every workgroup of a kernel came in and went out, on the constant
+// Measurement builds only (diag.hip.h, tools/stamps.py): when every workgroup of a kernel came in and went out, on the constant
 // 100 MHz clock -- a time line of the stream without a profiler attached.  One plain store per wave and event into a slot of its own
-// (the host takes minimum and maximum: atomics on one word from 4096 waves cost the scan 70 us).
-constexpr uint32_t kStampGroups = 8192; // workgroups a launch may have in a diagnostic build
+// (the host takes minimum and maximum: atomics on one word from 4096 waves cost the scan 70 us).  Empty in the product build.
+constexpr uint32_t kStampGroups = 8192; // workgroups a launch may have in a measurement build
 __device__ __forceinline__ void stamp(unsigned long long* st, uint32_t which)
 {
-#ifdef ADSB_AMD_STAMPS
-    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); // every wave for itself
-    if (st && (threadIdx.x & 63u) == 0 && w < kStampGroups) st[(size_t)which * kStampGroups + w] = (unsigned long long)wall_clock64();
-#else
-    (void)st, (void)which;
-#endif
+    if constexpr (diag::kStamps)
+    {
+        const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); // every wave for itself
+        if (st && (threadIdx.x & 63u) == 0 && w < kStampGroups) st[(size_t)which * kStampGroups + w] = (unsigned long long)wall_clock64();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -443,48 +432,35 @@ __device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWin
     if (FRONT && lane == 0 && g.g0 > 0) r.front = *reinterpret_cast<const uint16_t*>(g.buf + 2ull * (g.g0 - 1));
 }
 
-// A finished chunk: its record count for the ordering pass, and the count (clamped to the region size) added to the sum of its group
-// of kOrderChunks chunks -- the ordering pass starts from finished sums instead of running a summing kernel first.  The atomics need
-// no reply; each sum sits on its own cache line (256 additions per line over the whole scan).
-// Where the records of chunk `me` go: its own region, or (log mode) the next free entry of this wave's log; `logged` = records the wave
-// has in its log so far.  Everything is wave-uniform.
-__device__ __forceinline__ Emit begin_chunk(const ScanArgs& a, uint32_t me, uint32_t logged)
+// Where the records of chunk `me` go: its own region of `cap` raw records.  Everything is wave-uniform.
+__device__ __forceinline__ Emit begin_chunk(const ScanArgs& a, uint32_t me)
 {
     Emit e;
     e.count = 0;
-    if (a.log_cap)
-    {
-        e.start = blockIdx.x * a.log_cap + logged;
-        e.cap   = a.log_cap - logged;
-        e.base  = reinterpret_cast<uint4*>(a.chunk_records + e.start);
-    }
-    else
-    {
-        e.start = 0; // the ordering pass computes chunk * cap itself (64 bits)
-        e.cap   = a.cap;
-        e.base  = reinterpret_cast<uint4*>(a.chunk_records + (uint64_t)me * a.cap);
-    }
+    e.cap   = a.cap;
+    e.base  = reinterpret_cast<uint4*>(a.chunk_records + (uint64_t)me * a.cap);
     return e;
 }
 
-// What a finished chunk leaves for the ordering pass (wave-uniform).  It is written out (publish) half a chunk LATER, just in front of
+// What a finished chunk leaves for the ordering pass (wave-uniform): its record count (clamped to the region size) in the chunk directory, and
+// the same count added to the sum of its group of kOrderChunks chunks -- the ordering pass starts from finished sums instead of running a
+// summing kernel first.  The atomics need no reply; each sum sits on its own cache line (256 additions per line over the whole scan).
+// It is written out (publish) half a chunk LATER, just in front of
 // the next prefetch: a wave waits for its prefetched window with s_waitcnt vmcnt(0) at the top of every trip, vector-memory operations
 // complete in issue order, and a store or an atomic issued at the end of a trip -- acknowledged by the memory side a microsecond or two
 // later -- made that wait cover them (profiles/r04_sweep.txt).  In front of the prefetch they are older than the loads the wait is for.
 struct Pending
 {
-    uint32_t chunk, start, kept;
+    uint32_t chunk, kept;
     bool     over, valid;
 };
-__device__ __forceinline__ Pending finish_chunk(uint32_t chunk, const Emit& e, uint32_t* logged)
+__device__ __forceinline__ Pending finish_chunk(uint32_t chunk, const Emit& e)
 {
     Pending p;
     p.chunk = chunk;
-    p.start = e.start;
     p.kept  = e.count < e.cap ? e.count : e.cap;
     p.over  = e.count > e.cap;
     p.valid = true;
-    *logged += p.kept;
     return p;
 }
 __device__ __forceinline__ void publish(const ScanArgs& a, const Pending& p, int lane)
@@ -493,12 +469,10 @@ __device__ __forceinline__ void publish(const ScanArgs& a, const Pending& p, int
     // vector instructions this costs, but they act on the issuing XCD's L2 only -- tools/isa_probe.hip loses additions from different XCDs
     // to one word -- and a group of kOrderChunks chunks may straddle two XCD ranges.
     if (!p.valid || lane != 0) return;
-    *reinterpret_cast<uint2*>(a.chunk_dir + 2ull * p.chunk) = make_uint2(p.start, p.kept);
+    a.chunk_dir[p.chunk] = p.kept;
     uint32_t* sum = a.block_sums + (p.chunk / kOrderChunks) * kSumStride;
-#ifndef ADSB_AMD_DIAG_NO_SUMS // diagnostic builds (wrong results): what do the per-chunk additions cost?
     if (p.kept) atomicAdd(sum, p.kept);
     if (p.over) atomicOr(sum + 1, 1u);
-#endif
 }
 
 // Chunk order.  Workgroups b and b + nxcd share an XCD (round-robin dispatch).  The chunks are dealt out in groups of 16
@@ -523,9 +497,6 @@ struct WorkRange
     uint32_t xcd, sub, nxcd;
     uint32_t glog;       // log2 of the group size (ScanArgs::group_log2)
     uint32_t counter;    // index of the counter the wave draws from: its own (range), later a pool counter (kPoolBase + ..)
-#ifdef ADSB_AMD_DIAG_NO_GRAB
-    uint32_t diag_k = 0;
-#endif
     __device__ __forceinline__ uint32_t chunk_of(uint32_t v) const
     {
         const uint32_t gi = (v >> glog) * kSubRanges + sub; // group index inside the XCD
@@ -559,14 +530,8 @@ __device__ __forceinline__ WorkRange work_range(const ScanArgs& a)
     const uint32_t nxcd = a.nxcd;
     const uint32_t wg   = blockIdx.x / nxcd; // index of this workgroup among those of its XCD
     w.nslot             = gridDim.x / (nxcd * kSubRanges); // the grid is a multiple of nxcd * kSubRanges
-#ifdef ADSB_AMD_MIXED_COUNTERS // experiment (profiles/r04_sweep.txt): every counter is served by waves of ALL XCDs, so a slow XCD simply draws fewer tickets
-    const uint32_t nranges = nxcd * kSubRanges, r = wg % nranges;
-    w.slot                 = (wg / nranges) * nxcd + blockIdx.x % nxcd;
-    range_share(a, w, r / kSubRanges, r % kSubRanges);
-#else
     w.slot = wg / kSubRanges;
     range_share(a, w, blockIdx.x % nxcd, wg % kSubRanges);
-#endif
     return w;
 }
 // Taking the next work item is two steps for the same reason as Pending: the atomic is issued in front of the prefetch (grab_issue,
@@ -575,11 +540,7 @@ __device__ __forceinline__ WorkRange work_range(const ScanArgs& a)
 __device__ __forceinline__ uint32_t grab_issue(const ScanArgs& a, const WorkRange& w, int lane)
 {
     uint32_t v = 0;
-#ifdef ADSB_AMD_DIAG_NO_GRAB // diagnostic builds: a ticket without memory traffic (every wave counts for itself: fixed stride inside its counter's share)
-    v = w.slot + w.nslot * const_cast<WorkRange&>(w).diag_k++;
-#else
     if (lane == 0) v = atomicAdd(&a.work_counters[w.counter * kCounterStride], 1u);
-#endif
     return v;
 }
 __device__ __forceinline__ uint32_t grab_value(const WorkRange& w, uint32_t ticket)
@@ -592,16 +553,8 @@ __device__ __forceinline__ uint32_t grab_chunk(const ScanArgs& a, const WorkRang
 constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
 
 // The ticket drawn half a trip ago -> the chunk after `next`.  While the wave's counter has work that is its chunk_of(); when the counter
-// is dry the wave turns to another one's share for the rest of the launch (w then describes THAT counter: the tickets it draws from now on
-// are the victim's).  Why: the XCDs get equal shares but do not run equally fast -- the last wave of the fastest XCD left 205 us into a
-// launch, that of the slowest 228 us, which XCD is slow changes from launch to launch (profiles/r04_sweep.txt: waves out by XCD) -- and
-// the launch ends with its slowest XCD.  A thief reads all counters at once (lane c reads counter c: one load, L1 bypassed), works
-// out what each has left and draws from the one with the most (ties and near-ties broken by its own slot, so that the thieves spread).
-// A stale reading can only show MORE work than there is (counters only grow): a wasted draw, never a missed chunk.  Counters are only
-// ever advanced by agent-scope atomics, so any wave may draw from any of them; what is lost is the L2 hit on a stolen chunk's halo.
-// (First version: a shared word of "dry" bits, read and written by every thief with a returning atomic -- 4096 waves on one word at
-// the end of a launch cost more than the imbalance: 0.211 -> 0.25 ms.)
-// Small inputs (group_log2 == 0: a live buffer) do not steal: a handful of chunks, and the probes would cost more than they balance.
+// is dry the wave turns to the pool (below) for the rest of the launch.  (Two forms of work stealing between the XCDs' counters were
+// measured and made the kernel slower, 0.211 -> 0.24-0.28 ms: profiles/r04_sweep.txt.)
 __device__ __forceinline__ uint32_t take_next(const ScanArgs& a, WorkRange& w, uint32_t ticket, int lane)
 {
     // The pool (round 4).  The XCDs get equal shares of the recording but do not run equally fast: the last wave of the fastest XCD left 205 us
@@ -626,41 +579,7 @@ __device__ __forceinline__ uint32_t take_next(const ScanArgs& a, WorkRange& w, u
         const uint32_t c = a.main_chunks + (w.counter - kPoolBase) + t * npool;
         return c < a.total_chunks ? c : kNoChunk;
     }
-#if !defined(ADSB_AMD_STEAL) || !ADSB_AMD_STEAL
-    return kNoChunk; // measured and not kept (profiles/r04_sweep.txt): with the stealing below the kernel took 0.24-0.28 ms instead of 0.211
-#else
-    if (a.group_log2 == 0) return kNoChunk;
-    for (uint32_t tries = 0; tries < 4u; tries++)
-    {
-        uint32_t key = 0;
-        if ((uint32_t)lane < nranges)
-        {
-            WorkRange mine = w;
-            range_share(a, mine, (uint32_t)lane / kSubRanges, (uint32_t)lane % kSubRanges);
-            const uint32_t drawn = __hip_atomic_load(&a.work_counters[(uint32_t)lane * kCounterStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t taken = 2u * w.nslot + drawn;
-            const uint32_t left  = mine.end > taken ? mine.end - taken : 0u;
-            if (left) key = ((left < 0xFFFFu ? left : 0xFFFFu) >> 2 << 8) | ((((uint32_t)lane + w.slot) & 63u) << 2) | 1u; // most work first, in steps of four chunks
-        }
-        uint32_t best = 0;
-        for (uint32_t c = 0; c < nranges; c++)
-        {
-            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)c);
-            best             = k > best ? k : best;
-        }
-        if (best == 0) return kNoChunk;
-        const uint32_t victim = (uint32_t)__builtin_ctzll(ballot(key == best));
-        WorkRange      w2     = w;
-        range_share(a, w2, victim / kSubRanges, victim % kSubRanges);
-        const uint32_t v2 = grab_chunk(a, w2, lane);
-        if (v2 < w2.end)
-        {
-            w = w2;
-            return w.chunk_of(v2);
-        }
-    }
     return kNoChunk;
-#endif
 }
 
 } // namespace

@@ -29,6 +29,7 @@
 
 #include <stdint.h>
 
+#include "diag.hip.h"
 #include "rs978.h"
 #include "uat978.h"
 
@@ -948,8 +949,9 @@ struct StaleWindow
     }
 };
 
-// -DADSB_AMD_UAT_DIAG: shader-clock cycles of the demodulating wave by phase and kind of match, summed over a launch (tools/uat_diag.py)
-#ifdef ADSB_AMD_UAT_DIAG
+// Measurement builds (diag.hip.h, DIAG_UAT): shader-clock cycles of the demodulating wave by phase and kind of match, summed over a launch
+// (tools/uat_diag.py).  Every macro is empty in the product build.
+#if DIAG_UAT
 __device__ unsigned long long g_uat_diag[2][8]; // [kind][phase]; phase 7 = positions demodulated
 #define UAT_DIAG_DECLARE() unsigned long long diag_acc[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}}, diag_t = 0
 #define UAT_DIAG_BEGIN() diag_t = __builtin_readcyclecounter()
@@ -977,14 +979,9 @@ __device__ unsigned long long g_uat_diag[2][8]; // [kind][phase]; phase 7 = posi
 #endif
 enum { kDiagStage = 0, kDiagSync, kDiagSlice, kDiagSyndromes, kDiagDecode, kDiagMoreTiles, kDiagOutput };
 
-#ifndef ADSB_AMD_UAT_STAGE_INLINE
-#define ADSB_AMD_UAT_STAGE_INLINE 0
-#endif
-#ifndef ADSB_AMD_UAT_DEMOD_WAVES
-#define ADSB_AMD_UAT_DEMOD_WAVES 7
-#endif
+constexpr int kUatDemodWaves = 7; // per SIMD (67 vector registers; at eight the kernel spills and gains nothing, profiles/r04_uat978_demod_sweep.txt)
 template <bool PHASES_GIVEN>
-__global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
+__global__ __launch_bounds__(64, kUatDemodWaves) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
                                                        const RsTables* __restrict__ rs_tables, const uint32_t* __restrict__ cand, uint32_t ncand,
                                                        uat_rec_t* __restrict__ recs, uint8_t* __restrict__ payloads, uint8_t* __restrict__ uplink_payloads,
                                                        uint32_t uplink_cap,
@@ -1034,12 +1031,7 @@ __global__ __launch_bounds__(64, ADSB_AMD_UAT_DEMOD_WAVES) void uat_demod_kernel
         // stands in front of the loop over positions so that the ticket is a value of THIS loop: the inner one's exits count as
         // lane-varying, and a value carried through it would live in a vector register.)
         wave_fence(); // the previous match's readers are done with the tile
-#if ADSB_AMD_UAT_STAGE_INLINE
-#define UAT_STAGE_FIRST stage_dphi_body
-#else
-#define UAT_STAGE_FIRST stage_dphi
-#endif
-        const uint32_t next_item = nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)UAT_STAGE_FIRST<PHASES_GIVEN>(
+        const uint32_t next_item = nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_dphi<PHASES_GIVEN>(
                                                (g_cu16)in, (g_cu16)lut, n, (uint64_t)(word & 0x7FFFFFF8u), (lds_i16)dphi_s, lane, my_counter));
         // After the match's own frame: the frames the scan loop would take behind it through stale register bits (see StaleWindow).
         // They are demodulated by this wave, by the same code: the body below runs once per position.  All of this is wave-uniform.
@@ -1430,10 +1422,7 @@ __global__ __launch_bounds__(256) void uat_order_within_kernel(const uint32_t* _
 // Threads of a decision workgroup (4096 nodes each).  256 since round 4: with calls in flight the 1024-thread form waited for sixteen free wave
 // slots on one CU beside a demodulation kernel that fills every SIMD (13 -> 98 us resident); four waves find room.  Pipelined step 0.540-0.545 ->
 // 0.523-0.527 ms, calls back to back 0.750-0.754 -> 0.788-0.794 (the kernels themselves are slower with a quarter of the lanes).
-#ifndef ADSB_AMD_UAT_DECIDE_THREADS
-#define ADSB_AMD_UAT_DECIDE_THREADS 256
-#endif
-constexpr int kUatDecideThreads = ADSB_AMD_UAT_DECIDE_THREADS, kUatDecideLevels = 12, kUatNodesPerLane = (int)kUatDecideNodes / kUatDecideThreads;
+constexpr int kUatDecideThreads = 256, kUatDecideLevels = 12, kUatNodesPerLane = (int)kUatDecideNodes / kUatDecideThreads;
 static_assert((1u << kUatDecideLevels) == kUatDecideNodes, "2^levels successors cover a block");
 constexpr uint32_t kIndexMask = 0x7FFFFFFFu;
 
@@ -1670,7 +1659,7 @@ hipError_t launch_uat978_order(const UatArgs& a, uint32_t ncand, uint32_t* scrat
     return hipGetLastError();
 }
 
-#ifdef ADSB_AMD_UAT_DIAG
+#if DIAG_UAT
 extern "C" int adsb_amd_uat_diag(unsigned long long* out16)
 { // sums since the last call; the launches must have completed
     unsigned long long zero[16] = {0};

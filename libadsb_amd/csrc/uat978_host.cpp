@@ -760,10 +760,7 @@ struct adsb_amd_uat
         int             rc = 0;
         bool            queued = false, done = false;
     };
-#ifndef ADSB_AMD_UAT_SIDES
-#define ADSB_AMD_UAT_SIDES 3
-#endif
-    static constexpr int          kSides = ADSB_AMD_UAT_SIDES;
+    static constexpr int          kSides = 3;
     std::unique_ptr<adsb_amd_uat> twins[kSides - 1];
     std::thread                   workers[kSides]; // one per side, so that the GPU halves of two calls overlap each other too
     std::mutex                    pipe_mu;

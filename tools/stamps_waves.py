@@ -1,4 +1,4 @@
-"""When do the waves of one scan launch finish?  (-DADSB_AMD_STAMPS build)  Per XCD (workgroup index % 8) and per work counter: the time of the
+"""When do the waves of one scan launch finish?  (measurement build: -DADSB_AMD_DIAG_BUILD=1 -DDIAG_STAMPS=1, diag.hip.h)  Per XCD (workgroup index % 8) and per work counter: the time of the
 last wave out, relative to the first wave in.
     python tools/stamps_waves.py ab_libs/stamps.so"""
 import ctypes as C, os, sys
