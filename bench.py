@@ -321,6 +321,26 @@ def bench_1090_single(args, local_rank, A, synth, torch):
         res.feed(rec, BB // 2, nbuf, collect=False)
         resolve_s = min(resolve_s, time.perf_counter() - t1)
     res.close()
+    # The replay as a whole, measured: the scan of step k + 1 runs on the GPU while this thread resolves the records of step k (one
+    # resolver for the whole loop, as a long-running handler has).  This is the decoded-messages rate of a recorded-file job on one GPU;
+    # it is bound by the sequential host half (host_resolve_ms per step), `value` above is the GPU side alone.
+    pipe = None
+    if not args.serial:
+        resp = A.Resolver(mode=args.rate, sample_clock_hz=100000 * args.rate)
+        psteps = max(4, min(args.steps, 40))
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        got = 0
+        sc.submit(d_iq.data_ptr(), nbytes, BB, stream, 0)
+        for i in range(1, psteps):
+            sc.submit(d_iq.data_ptr(), nbytes, BB, stream, i & 1)
+            got += resp.feed(sc.fetch_packed((i - 1) & 1, copy=False), BB // 2, nbuf, collect=False)[0]
+        got += resp.feed(sc.fetch_packed((psteps - 1) & 1, copy=False), BB // 2, nbuf, collect=False)[0]
+        ep = time.perf_counter() - tp
+        resp.close()
+        pipe = {"steps": psteps, "ms_per_step": round(ep / psteps * 1e3, 4), "msamples_per_s": round(samples * psteps / ep / 1e6, 1),
+                "decoded_msgs_per_s": round(got / ep, 1), "decoded_msgs_per_step": round(got / psteps, 1),
+                "what": "scan of step k+1 on the GPU under the host's resolve of step k (one thread + the resolver's helper), no listener"}
     out = {
         "metric": "Msamples/s demodulated (1090ES u8 IQ -> Mode S frame records)",
         "value": round(samples * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -338,22 +358,26 @@ def bench_1090_single(args, local_rank, A, synth, torch):
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(nbytes if args.rate == 20 else "mode2400:%d" % nbytes),
                      "kernel": "scan1090_kernel" if args.rate == 20 else "scan2400_kernel", "kernel_ms": round(kernel_ms, 4),
                      "kernel_ms_source": "HIP events on the kernel's dispatch (hipExtLaunchKernelGGL start/stop events, the stream the scan is launched on), "
-                                         "%d of the %d timed launches (every %s)" % (k_n, args.steps, args.time_every),
+                                         "%d of the %d timed launches (every %s), in the pipelined loop: the copy engine moves the previous step's records "
+                                         "to the host beside the kernel, which costs it about 2-5 %% -- rocprofv3 of `bench.py --serial` (profiles/) has no "
+                                         "copy beside the kernel and reads that much lower" % (k_n, args.steps, args.time_every),
                      "kernel_ms_first_100": round(k100 / max(1, n100), 4),
                      "algorithmic_bytes": int(alg_bytes)},
         "records_per_step": nrec, "frames_injected": injected,
         "decoded_msgs_per_step_rank0": int(accepted),
-        # frames through the sequential host half (ICAO cache, decode, CPR, aircraft state): the GPU hands over records for
-        # `accepted` frames per step in ms_per_step, the host resolves them in host_resolve_ms on one core; a pipeline of the
-        # two sustains the slower of the two rates (the host's)
-        "decoded_msgs_per_s": round(min(accepted * args.steps / elapsed, accepted / max(resolve_s, 1e-9)), 1),
-        "decoded_msgs_per_s_gpu_side": round(accepted * args.steps / elapsed, 1),
+        # frames through the sequential host half (ICAO cache, decode, CPR, aircraft state): measured in a loop that resolves step k on the
+        # host while the GPU scans step k + 1 (`pipelined`); with --serial, the slower of the two separately timed halves
+        "decoded_msgs_per_s": pipe["decoded_msgs_per_s"] if pipe else round(min(accepted * args.steps / elapsed, accepted / max(resolve_s, 1e-9)), 1),
+        "pipelined": pipe,
         "gpu_enqueue_to_count_ms": round(t_ms / k_n, 4),
         "host_resolve_ms_rank0": round(resolve_s * 1e3, 2),
         "host_resolve_note": "records + GPU-decoded fields -> ICAO gating, skip-ahead (helper thread) | batched CPR, aircraft update (calling thread), no listener; best of 5 stretches",
     }
     if not args.no_extras:
         out["end_to_end"] = end_to_end_1090(A, rec, iq_host, BB, nbuf, accepted)
+        if pipe:
+            out["end_to_end"]["pipelined_msamples_per_s"] = pipe["msamples_per_s"]
+            out["end_to_end"]["pipelined_decoded_msgs_per_s"] = pipe["decoded_msgs_per_s"]
         # the "2.4 MS/s" flavour of the same configuration (BASELINE.json's wording): the library's own mode for that rate, see --rate
         try:
             iq24, inj24 = synth.fill_range(0, nbuf, nthreads=ncpu, rate_x10=24)
@@ -550,6 +574,11 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
     capt = torch.tensor([n0 + n0 // 4 + 4096], dtype=torch.int64, device="cuda" if on_device else "cpu")
     dist.all_reduce(capt, op=dist.ReduceOp.MAX)
     cap = int(capt.item())
+    # how many ranks the collective backend itself has seen (a sum of ones over RCCL / gloo at set-up): the SCALE record shows it beside
+    # ranks_seen, which counts the headers that arrived through the shared control page
+    ones = torch.ones(1, dtype=torch.int64, device="cuda" if on_device else "cpu")
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    backend_ranks_seen = int(ones.item())
     # How the records reach rank 0's host.  Default: every GPU writes its records over its own PCIe link into a page-locked segment
     # of node-shared host memory and only 32-byte headers are gathered (shard.NodeGather) -- with a gather of the records themselves
     # (shard.RootGather: xGMI to rank 0's GPU, then its one host link) rank 0's PCIe link carries N x 9 MB per step and bounds the job
@@ -764,6 +793,7 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
             "end_to_end_note": "value counts delivery of the sorted records to rank 0's host (per-rank segments in recording order, which the "
                                "resolver reads in place); end_to_end adds rank 0 resolving every delivered step (one core) in the same loop",
             "ranks_seen": int(seen["min"]) if ng is not None else world,
+            "rccl_ranks_seen": backend_ranks_seen, "collective_backend": "RCCL (torch.distributed nccl)" if on_device else "gloo (rehearsal)",
             "kernel_ms_by_rank": {"min": round(min(per_rank), 4), "max": round(max(per_rank), 4), "slowest_rank": int(per_rank.index(max(per_rank))),
                                   "all": [round(x, 4) for x in per_rank]},
             "independent_shards_value": round(samples_all * args.steps / indep / 1e6, 1),

@@ -265,6 +265,19 @@ long adsb_amd_handler_handle_data(adsb_amd_handler_t* h, const uint8_t* iq_host,
 int  adsb_amd_host_alloc(void** out, size_t nbytes);
 void adsb_amd_host_free(void* p);
 
+/* The recorded-file job over several GPUs of one node (BASELINE configs[3]; nothing the reference has: its one receiver thread is
+ * RTLSDR.hpp:470-473) hands each rank's sorted records to the resolving rank through node-shared host memory; a step's 32-byte header
+ * {count, first buffer, rank, step} goes through a control page that several PROCESSES map.  These are the only accesses to that page:
+ * C11 release / acquire on naturally aligned 64-bit words, so that the ordering "a header the root can see implies records it can see"
+ * does not rest on an interpreter's call boundaries or on one architecture's store order.
+ *   post_header   three relaxed stores (count, first buffer, rank), then `step` with release into slot[3]
+ *   read_header   acquire load of slot[3]; 0 when it is below min_step, else the four words in out[] and 1
+ *   store_release / load_acquire: the credit word (last step the resolving rank has finished reading) */
+void    adsb_amd_shm_post_header(int64_t* slot, int64_t count, int64_t first_buffer, int64_t rank, int64_t step);
+int     adsb_amd_shm_read_header(const int64_t* slot, int64_t min_step, int64_t* out4);
+void    adsb_amd_shm_store_release(int64_t* word, int64_t value);
+int64_t adsb_amd_shm_load_acquire(const int64_t* word);
+
 /* Recorded-file replay, one pass: what RTLSDR::TestDataReadLoop (RTLSDR.hpp:419-442) feeds a handler -- whole 262144-byte
  * buffers in file order, each demodulated on its own, a trailing partial buffer never delivered -- over buffers
  * [first_buffer, first_buffer + max_buffers) of the file (ranks of a multi-GPU job take disjoint ranges; the resolver state

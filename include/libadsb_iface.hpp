@@ -117,10 +117,11 @@ struct RTLSDR
     static constexpr size_t BufferLength = size_t{65536u} * 4u;
     static constexpr size_t BufferCount  = 16;
     struct DeviceInfo
-    {
-        char vendor[256];
-        char product[256];
-        char serial[256];
+    { // same members in the same order as the reference's (RTLSDR.hpp:67-73): a selector compiled against either header reads the same bytes
+        uint32_t index;
+        char     vendor[256];
+        char     product[256];
+        char     serial[256];
     };
     struct IDeviceSelector
     {

@@ -39,6 +39,7 @@ EXPORTS = [
     "adsb_amd_resolver_create", "adsb_amd_resolver_destroy", "adsb_amd_resolver_set_sample_clock", "adsb_amd_resolver_feed",
     "adsb_amd_resolver_aircraft_count", "adsb_amd_count_callback", "adsb_amd_handler_create", "adsb_amd_handler_destroy", "adsb_amd_handler_last_error",
     "adsb_amd_handler_set_sample_clock", "adsb_amd_handler_handle_data", "adsb_amd_handler_replay_file", "adsb_amd_handler_run_replay", "adsb_amd_host_alloc", "adsb_amd_host_free",
+    "adsb_amd_shm_post_header", "adsb_amd_shm_read_header", "adsb_amd_shm_store_release", "adsb_amd_shm_load_acquire",
     "adsb_amd_transport_create", "adsb_amd_transport_destroy", "adsb_amd_transport_start", "adsb_amd_transport_stop", "adsb_amd_transport_push",
     "adsb_amd_transport_stats",
     "adsb_amd_uat_create", "adsb_amd_uat_destroy", "adsb_amd_uat_last_error", "adsb_amd_uat_handle_data", "adsb_amd_uat_set_carry_full", "adsb_amd_uat_set_host_loop", "adsb_amd_uat_set_extra_capacity",
@@ -128,6 +129,13 @@ def lib():
         L.adsb_amd_transport_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.adsb_amd_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         L.adsb_amd_host_free.argtypes = [C.c_void_p]
+        L.adsb_amd_shm_post_header.argtypes = [C.c_void_p] + [C.c_int64] * 4
+        L.adsb_amd_shm_post_header.restype = None
+        L.adsb_amd_shm_read_header.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.adsb_amd_shm_store_release.argtypes = [C.c_void_p, C.c_int64]
+        L.adsb_amd_shm_store_release.restype = None
+        L.adsb_amd_shm_load_acquire.argtypes = [C.c_void_p]
+        L.adsb_amd_shm_load_acquire.restype = C.c_int64
         L.adsb_amd_uat_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
         L.adsb_amd_uat_destroy.argtypes = [C.c_void_p]
         L.adsb_amd_uat_last_error.argtypes = [C.c_void_p]

@@ -250,6 +250,27 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
 
 extern "C" const char* adsb_amd_version(void) { return "libadsb_amd 0.1 (gfx950)"; }
 
+// ---- control page of the node-shared record hand-over (shard.NodeGather): see adsb_amd.h
+extern "C" void adsb_amd_shm_post_header(int64_t* slot, int64_t count, int64_t first_buffer, int64_t rank, int64_t step)
+{
+    __atomic_store_n(&slot[0], count, __ATOMIC_RELAXED);
+    __atomic_store_n(&slot[1], first_buffer, __ATOMIC_RELAXED);
+    __atomic_store_n(&slot[2], rank, __ATOMIC_RELAXED);
+    __atomic_store_n(&slot[3], step, __ATOMIC_RELEASE); // last: whoever reads this step with acquire sees the three words and the records before them
+}
+extern "C" int adsb_amd_shm_read_header(const int64_t* slot, int64_t min_step, int64_t* out4)
+{
+    const int64_t step = __atomic_load_n(&slot[3], __ATOMIC_ACQUIRE);
+    if (step < min_step) return 0;
+    out4[0] = __atomic_load_n(&slot[0], __ATOMIC_RELAXED);
+    out4[1] = __atomic_load_n(&slot[1], __ATOMIC_RELAXED);
+    out4[2] = __atomic_load_n(&slot[2], __ATOMIC_RELAXED);
+    out4[3] = step;
+    return 1;
+}
+extern "C" void    adsb_amd_shm_store_release(int64_t* word, int64_t value) { __atomic_store_n(word, value, __ATOMIC_RELEASE); }
+extern "C" int64_t adsb_amd_shm_load_acquire(const int64_t* word) { return __atomic_load_n(word, __ATOMIC_ACQUIRE); }
+
 extern "C" int adsb_amd_create(adsb_amd_ctx_t** out, int device) { return adsb_amd_create_mode(out, device, ADSB_AMD_MODE_2000); }
 
 extern "C" int adsb_amd_create_mode(adsb_amd_ctx_t** out, int device, int mode)

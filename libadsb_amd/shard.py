@@ -150,9 +150,12 @@ class NodeGather:
     step k + 1 while the root still reads step k).  Every rank maps the file; a rank registers only ITS OWN two segments with the HIP
     runtime (they are the only ones its GPU writes: its scanner copies the step's records straight from HBM into `records_ptr(step)`
     over its own PCIe link), the root reads the others through the plain mapping.  `gather(step, count, first_buffer, event=...)`
-    notes the step's 32-byte header (count, first buffer, rank, step); it is WRITTEN into the rank's slot of the control page by the
-    rank's host thread once `event` -- recorded on the stream behind the copy -- has completed (flush(): at the rank's next gather /
-    acquire, or when it is called), the step number last, so a header the root can see implies records it can see.  The root polls the
+    posts the step's 32-byte header (count, first buffer, rank, step): it is WRITTEN into the rank's slot of the control page by the
+    rank's host thread once `event` -- recorded on the stream behind the copy -- has completed, the step number last and with release
+    semantics (adsb_amd_shm_post_header: C11 atomics in libadsb_amd.so, not interpreter stores), so a header the root can see implies
+    records it can see.  By default gather() does that before it returns (it waits for the event); with wait=False the header is only
+    NOTED and goes out at the rank's next gather / acquire / flush / close -- the pipelined loop's form, where by then the copy is long
+    done.  The root polls the
     slots (collect(), bounded) and gets one (records view, first buffer) pair per rank, in rank = recording order; the resolver
     consumes them one after the other without a copy (`concatenate` makes one array with recording-wide buffer indices where one is
     wanted).  Nothing per step goes through torch.distributed: the collective that used to carry the headers put one RCCL kernel per
@@ -186,6 +189,9 @@ class NodeGather:
         self._map = None
         self._np = None
         self._registered = []
+        self._posted = []  # headers noted but not yet written: (step, count, first buffer, event)
+        from . import lib as _native
+        self._L = _native()  # the control page is only ever touched through its release / acquire helpers
         # The name carries a nonce chosen by the root for this instance (two jobs, or two instances of one job, never meet in one
         # file) and the file is created exclusively.
         nonce = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -224,11 +230,11 @@ class NodeGather:
                 finally:
                     os.close(fd)
                 self._np = np.frombuffer(self._map, dtype=np.uint8)
-                self._ctl = self._np[:self.PAGE].view(np.int64)  # [0]: last step the root has finished reading, -1 before any
+                self._ctl_addr = self._np.ctypes.data  # the control page as int64 words: [0] last step the root has finished reading, -1 before any
                 if self.rank == root:
-                    self._ctl[0] = -1
+                    self._L.adsb_amd_shm_store_release(self._word(0), -1)
                 for par in (0, 1):
-                    self._ctl[self._slot(self.rank, par) + 3] = -1  # no step posted yet
+                    self._L.adsb_amd_shm_post_header(self._word(self._slot(self.rank, par)), 0, 0, self.rank, -1)  # no step posted yet
                 for step in (0, 1):  # first touch of this rank's own segments (on the NUMA node this rank runs on)
                     o = self._offset(self.rank, step)
                     self._np[o:o + self.seg] = 0
@@ -249,7 +255,6 @@ class NodeGather:
         if not int(ok.item()):
             self.close()
             raise OSError("node-shared record segment could not be set up on every rank")
-        self._posted = []  # headers noted but not yet written: (step, count, first buffer, event)
         self.ranks_seen = 0
 
     def _slot(self, rank, step):
@@ -258,35 +263,40 @@ class NodeGather:
     def _offset(self, rank, step):
         return self.PAGE + (rank * 2 + (step & 1)) * self.seg
 
+    def _word(self, index):
+        """Address of int64 word `index` of the control page."""
+        return self._ctl_addr + 8 * index
+
+    def _released(self):
+        return int(self._L.adsb_amd_shm_load_acquire(self._word(0)))
+
     def flush(self):
         """Write the headers noted so far into this rank's slot of the control page, oldest first, each once its event has completed
         (waits for it: by the time this is called -- the rank's next step, or the end of a loop -- the copy is long done)."""
-        for step, count, first, event in self._posted:
+        posted, self._posted = self._posted, []
+        for step, count, first, event in posted:
             if event is not None:
                 event.synchronize()
-            base = self._slot(self.rank, step)
-            self._ctl[base], self._ctl[base + 1], self._ctl[base + 2] = count, first, self.rank
-            self._ctl[base + 3] = step  # last: x86 stores become visible in program order, and the reader reads it first
-        self._posted = []
+            self._L.adsb_amd_shm_post_header(self._word(self._slot(self.rank, step)), count, first, self.rank, step)
 
     def acquire(self, step):
         """Before this rank's segment of `step` is written: wait until the root has finished reading step - 2 (same segment)."""
         self.flush()  # the header of the step before, if its copy has an event: the root may be waiting for it before it releases
         need = step - 2
-        if need < 0 or int(self._ctl[0]) >= need:
+        if need < 0 or self._released() >= need:
             return
         import time
         deadline = time.monotonic() + self.acquire_timeout_s
-        while int(self._ctl[0]) < need:
+        while self._released() < need:
             if time.monotonic() > deadline:
                 raise TimeoutError("rank %d: the root has not released step %d after %.0f s (last released: %d)"
-                                   % (self.rank, need, self.acquire_timeout_s, int(self._ctl[0])))
+                                   % (self.rank, need, self.acquire_timeout_s, self._released()))
             time.sleep(0)
 
     def release(self, step):
         """Root: the views of `step` (and of every earlier step) will not be read any more."""
-        if self.rank == self.root and int(self._ctl[0]) < step:
-            self._ctl[0] = step
+        if self.rank == self.root and self._released() < step:
+            self._L.adsb_amd_shm_store_release(self._word(0), int(step))
 
     def records_ptr(self, step):
         """Host address (page-locked, device-writable) where this rank's records of `step` go.  Call acquire(step) first."""
@@ -300,16 +310,18 @@ class NodeGather:
     def gather(self, step, count, first_buffer, wait=True, event=None):
         """`count` records of this rank lie (or, with `event`, will lie once it has completed) in its segment of `step`.  Not a
         collective.  Returns on the root [(records, first_buffer)] per rank (views of the shared segments, valid until
-        release(step)), elsewhere None.  wait=False: the root gets a handle whose result() gives the same once every rank's header
-        of the step is there -- so that it can enqueue step k + 1 before it looks at step k, like the other ranks do.  A rank that
-        passes an event (on "nccl" none given means: one recorded here, on the current stream) must come back (gather / acquire /
-        flush) for its header to be written."""
+        release(step)), elsewhere None.
+        wait=True (default): self-completing -- the call waits for the event (on "nccl" none given means: one recorded here, on the
+        current stream) and writes this rank's header before it returns; the root then waits for every rank's header.
+        wait=False: the pipelined form.  The header is only noted; it is written when the rank comes back (its next gather / acquire,
+        flush(), or close()), by when the copy is long done, and the root gets a handle whose result() gives the views once every
+        rank's header of the step is there -- so that it can enqueue step k + 1 before it looks at step k, like the other ranks do."""
         if count > self.cap:
             raise RuntimeError("rank %d produced %d records, its segment holds %d" % (self.rank, count, self.cap))
         if event is None and self.on_device:
             event = torch.cuda.current_stream().record_event()  # the records were copied on the current stream (the documented use)
         self._posted.append((int(step), int(count), int(first_buffer), event))
-        if event is None:
+        if wait or event is None:
             self.flush()
         if self.rank != self.root:
             return None
@@ -322,14 +334,16 @@ class NodeGather:
         self.flush()
         deadline = time.monotonic() + self.acquire_timeout_s
         out, r = [], 0
+        hdr = np.zeros(4, dtype=np.int64)
         while r < self.world:
-            base = self._slot(r, step)
-            if int(self._ctl[base + 3]) < step:
+            base = self._word(self._slot(r, step))
+            if not self._L.adsb_amd_shm_read_header(base, int(step), hdr.ctypes.data):
                 if time.monotonic() > deadline:
-                    raise TimeoutError("root: no header of rank %d for step %d after %.0f s (its last: step %d)" % (r, step, self.acquire_timeout_s, int(self._ctl[base + 3])))
+                    self._L.adsb_amd_shm_read_header(base, -(1 << 62), hdr.ctypes.data)
+                    raise TimeoutError("root: no header of rank %d for step %d after %.0f s (its last: step %d)" % (r, step, self.acquire_timeout_s, int(hdr[3])))
                 time.sleep(0)
                 continue
-            n, first, who, st = (int(self._ctl[base + k]) for k in range(4))
+            n, first, who, st = (int(x) for x in hdr)
             if st != step or who != r:
                 raise RuntimeError("header of rank %d for step %d carries step %d, rank %d" % (r, step, st, who))
             o = self._offset(r, step)
@@ -350,17 +364,30 @@ class NodeGather:
         return np.concatenate(recs) if recs else np.zeros(0, RECORD_DTYPE)
 
     def close(self):
+        """Also writes out any header that was only noted (a rank's last step in the pipelined form): a rank that is done does not
+        leave the root waiting for it."""
+        if self._np is not None and self._posted:
+            try:
+                self.flush()
+            except Exception:  # a failed device at teardown must not mask the error that brought us here
+                self._posted = []
         for ptr in self._registered:
             torch.cuda.cudart().cudaHostUnregister(ptr)
         self._registered = []
         self._np = None
-        self._ctl = None
+        self._ctl_addr = None
         if self._map is not None:
             try:
                 self._map.close()
             except BufferError:
                 pass  # views handed out are still alive; the mapping goes with the process
             self._map = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Watchdog:

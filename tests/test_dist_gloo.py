@@ -86,8 +86,10 @@ lazy = shard.NodeGather(16, tag='lazy', acquire_timeout_s=0.3)
 ev = Ev()
 lazy.acquire(0)
 lazy.host_records_view(0)[:2] = local[:2]
+def posted_step(g, step):  # the step number in this rank's header slot of the control page
+    return int(g._L.adsb_amd_shm_load_acquire(g._word(g._slot(rank, step) + 3)))
 h = lazy.gather(0, 2, first, wait=False, event=ev)
-assert not ev.waited and int(lazy._ctl[lazy._slot(rank, 0) + 3]) == -1
+assert not ev.waited and posted_step(lazy, 0) == -1
 if rank == 0:
     try:
         if world > 1:
@@ -97,11 +99,34 @@ if rank == 0:
         assert 'rank 1' in str(e)
 dist.barrier()
 lazy.flush()
-assert ev.waited and int(lazy._ctl[lazy._slot(rank, 0) + 3]) == 0
+assert ev.waited and posted_step(lazy, 0) == 0
 dist.barrier()
 if rank == 0:
     parts = h.result()
     assert lazy.ranks_seen == world and all(len(p) == 2 for p, _ in parts)
+    lazy.release(0)
+# the default form is self-completing: gather() waits for the event and posts the header before it returns (no "must come back" rule)
+ev1 = Ev()
+lazy.acquire(1)
+lazy.host_records_view(1)[:1] = local[:1]
+parts = lazy.gather(1, 1, first, event=ev1)
+assert ev1.waited and posted_step(lazy, 1) == 1
+assert (parts is not None) == (rank == 0)
+if rank == 0:
+    assert all(len(p) == 1 for p, _ in parts)
+    lazy.release(1)
+# and a header that was only noted goes out when the rank closes its side (a rank's last step in the pipelined form)
+dist.barrier()
+ev2 = Ev()
+lazy.acquire(2)
+h2 = lazy.gather(2, 0, first, wait=False, event=ev2)
+if rank != 0:
+    lazy.close()
+    assert ev2.waited
+dist.barrier()
+if rank == 0:
+    assert len(h2.result()) == world
+    lazy.close()
 # flow control: without a release the writer of step + 2 must not get its segment
 slow = shard.NodeGather(8, tag='credit', acquire_timeout_s=0.3)
 for step in range(2):
@@ -164,6 +189,85 @@ def test_two_rank_gather_and_resolve(tmp_path, native_libs, world, port):
                           "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "OK" in out.stdout and "ROOT-GATHER-OK" in out.stdout and "NODE-GATHER-OK" in out.stdout
+
+
+# BASELINE configs[3] is 32 768 buffers over 8 GPUs.  Its partition arithmetic, and the hand-over with eight ranks on a small recording:
+# uneven shards (11 buffers), ranks with nothing to scan (5 buffers), the pipelined (noted-header) form the bench uses, and a rank that
+# cannot set its segment up at each construction stage -> every rank falls back to the record gather together.
+WORKER8 = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import numpy as np
+import torch.distributed as dist
+import libadsb_amd as A
+from libadsb_amd import synth, shard
+import helpers as H
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 8
+BB = A.REF_BUFFER_BYTES
+assert shard.shard_range(32768, rank, 8) == (4096 * rank, 4096)  # the configuration itself: 1 GiB per GPU, no remainder
+for NBUF in (11, 5):
+    first, count = shard.shard_range(NBUF, rank, world)
+    assert count in ((1, 2) if NBUF == 11 else (0, 1))
+    iq = synth.fill_range(first, count)[0] if count else np.zeros(0, np.uint8)
+    local = H.expected_records(iq, BB) if count else np.zeros(0, A.RECORD_DTYPE)
+    ng = shard.NodeGather(2000, tag='w8-%%d' %% NBUF)
+    full = synth.fill_range(0, NBUF)[0] if rank == 0 else None
+    want = H.expected_records(full, BB) if rank == 0 else None
+    prev = None
+    for step in range(5):  # the bench's loop: note the header, come back a step later
+        ng.acquire(step)
+        ng.host_records_view(step)[:len(local)] = local
+        h = ng.gather(step, len(local), first, wait=False)
+        if prev is not None and rank == 0:
+            parts = prev.result()
+            assert ng.ranks_seen == 8 and [f for _, f in parts] == [shard.shard_range(NBUF, r, 8)[0] for r in range(8)]
+            H.assert_records_equal(shard.NodeGather.concatenate(parts), want)
+            ng.release(prev.step)
+        prev = h
+    if rank == 0:
+        parts = prev.result()
+        got = shard.NodeGather.concatenate(parts)
+        H.assert_records_equal(got, want)
+        n, fr, ac = A.Resolver().feed(got, BB // 2, NBUF)
+        ofr, oac = H.oracle_run(full, BB)
+        H.assert_streams_equal(fr, ac, ofr, oac)
+        ng.release(prev.step)
+    ng.close()
+    for stage, who in (('file', 0), ('map', 5), ('register', 7)):
+        shard.NodeGather._fail_rank_for_tests = (who, stage)
+        try:
+            shard.NodeGather(16, tag='w8-fail-' + stage)
+            ok = stage == 'register'  # gloo: nothing is registered, so that stage cannot fail here
+        except OSError:
+            ok = stage != 'register'
+        shard.NodeGather._fail_rank_for_tests = None
+        assert ok, stage
+        fb = shard.RootGather(2000)  # all eight ranks build the fallback together and it delivers the same stream
+        fb.host_records_view()[:len(local)] = local
+        got = fb.gather(len(local), first)
+        if rank == 0:
+            H.assert_records_equal(got, want)
+        else:
+            assert got is None
+import glob
+assert not glob.glob('/dev/shm/libadsb_amd_gather_*w8-*'), 'no file may be left behind'
+if rank == 0:
+    print('EIGHT-RANK-OK')
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_eight_rank_rehearsal_of_the_recorded_file_partition(tmp_path, native_libs):
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8 % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                          "--master-port", "29519", str(script)], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "EIGHT-RANK-OK" in out.stdout
 
 
 def test_bench_started_bare_launches_its_own_ranks(monkeypatch):
