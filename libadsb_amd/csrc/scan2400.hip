@@ -8,10 +8,17 @@
 // Shape, the 2 MS/s kernel's: persistent single-wave workgroups walk XCD-local chunk ranges off work counters, the next chunk's
 // window is prefetched into registers while the current one is processed:
 //   * a wave owns 4096 preamble positions of one buffer, loads the 4416 samples they can touch with 16-byte coalesced loads and
-//     parks s = (I-127)^2 + (Q-127)^2 in the same interleaved LDS image (dword q = s[q] | s[q + 2048] << 16), so one packed
-//     operation serves two positions and "sample q + a" is dword q + a for every a;
-//   * the gate runs dense and packed on that image: pair sums of the four pulse regions against the sum of eight quiet samples,
-//     saturating 16-bit adds, survivors to a queue;
+//     parks s = (I-127)^2 + (Q-127)^2 as a LINEAR image of halves in LDS (sample p of the chunk at half p + 8);
+//   * the gate (oracle2400_gate) runs in two steps since round 5.  Dense, on the MATRIX pipe: a necessary condition that is linear in s,
+//         (s0+s1) + (s2+s3) + (s8+s9) > 2 (s-1 + s5+s6+s7 + s14+s15+s16+s17)
+//     (3 min(A,B,C,D) > 2 Q implies 3 (A+B+C)/3 > 2 Q), evaluated for 1024 positions at a time as a banded (Toeplitz) matrix product with
+//     v_mfma_i32_32x32x32_i8: the image itself is the B operand -- 32 columns, column c = the 64 samples from 32 c - 8 on, read as bytes
+//     (low byte, high byte of every half) --, the A operand holds the filter's weights for the 32 positions of a column, once for the low
+//     bytes and once for the high bytes (an i8 weight cannot carry the factor 256 between them: two accumulators, combined with one
+//     shift-add).  The vector unit only combines, collects sign bits and XORs bit 7 of the low bytes (the matrix cores multiply signed
+//     bytes: low byte ^ 0x80 is low byte - 128, a constant per filter that the accumulators' initial values take out): about 4 vector
+//     instructions per 64 positions where the packed 16-bit gate took 8.3.  The survivors of that condition (about forty per chunk) go
+//     through the exact gate sparsely, a lane each;
 //   * a candidate is demodulated by the whole wave: first the preamble correlation of the five sub-sample phases, on registers
 //     (each row of 16 lanes holds the 13 magnitudes once, weighted for its phase, DPP row sums) -- most gate survivors of noise
 //     end there; then per phase tried lane b slices bit b and bit 64 + b from four samples with the overlap weights of its own
@@ -31,32 +38,34 @@ namespace adsb_amd
 namespace
 {
 
-constexpr int kSpan24     = 292;                          // samples after j a candidate may read (oracle2400.c)
-constexpr int kHalo24     = 320;                          // halo dwords of the image (>= kSpan24, a multiple of 8)
-constexpr int kImgBase    = 4;                            // dword of the image's q = 0; dword 3 = (sample before the chunk | s[2047] << 16)
-constexpr int kImgDwords  = kImgBase + kHalfChunk + kHalo24 + 4;
-constexpr int kQueue24    = 64;                           // queue entries per pass (a lane holds at most 64)
+constexpr int kSpan24    = 292;                       // samples after j a candidate may read (oracle2400.c)
+constexpr int kHalo24    = 320;                       // halo samples of the image (>= kSpan24, a multiple of 8)
+constexpr int kImgPad    = 8;                         // halves in front of the chunk's first sample: sample p lives at half p + kImgPad, so that a lane's
+                                                      // eight samples land on a 16-byte boundary AND a column of the matrix product starts on one
+                                                      // (only the last of the eight, the sample before the chunk, is ever read with a non-zero weight)
+constexpr int kImgHalves = kImgPad + kChunk + kHalo24; // 4424 halves = 8848 bytes
+constexpr int kQueue24   = 64;                        // queue entries per pass (a lane holds at most 64)
+constexpr int kGateBlock = 1024;                      // positions per matrix product: 32 columns of 32 positions
+static_assert(kChunk % kGateBlock == 0 && kImgHalves % 8 == 0, "whole blocks, 16-byte rows");
+// the last column of the last block reads 64 samples from sample 4096 - 32 - 8 on: inside the halo
+static_assert(kChunk - 32 - kImgPad + 64 <= kChunk + kHalo24, "the matrix product's reads stay inside the image");
 
-__device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b)
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef float    f16_t __attribute__((ext_vector_type(16)));
+
+// Weight of tap a (sample j + a) in the necessary condition A + B + C - 2 Q > 0 of position j
+constexpr int prefilter_weight(int a)
 {
-    uint32_t r;
-    asm("v_pk_add_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    return (a == 0 || a == 1 || a == 2 || a == 3 || a == 8 || a == 9) ? 1 : (a == -1 || a == 5 || a == 6 || a == 7 || (a >= 14 && a <= 17)) ? -2 : 0;
 }
-__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b)
-{
-    uint32_t r;
-    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_min(as_pk(a), as_pk(b))); }
-// the same, opaque to the compiler: min(x, 1) per half written in C turns into two compares, two selects and a permute
-__device__ __forceinline__ uint32_t pk_min_asm(uint32_t a, uint32_t b)
-{
-    uint32_t r;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// The product runs on v_mfma_f32_32x32x16_f16: the halves of the image are converted to f16 on the way in (round to nearest: off by at most
+// 2^-11 of the value), the products of two f16 numbers are exact in f32, the sum is an f32 sum.  The condition stays NECESSARY because the weights
+// lean the right way -- a pulse sample counts 1 + 2^-10 (s <= fl(s) (1 + 2^-10)), a quiet one 2 (1 - 2^-11) (s >= fl(s) (1 - 2^-11)) -- and the
+// accumulators start from +4, more than sixty-four f32 additions of numbers below 2^20 can lose.  (An integer product -- i8, low and high bytes of
+// the halves as two chains, exact -- was built first: twice the matrix instructions, twice the LDS reads, a shift, an XOR and a combine per
+// register where this form has the conversions; measured no faster than the packed gate it replaced, profiles/r05_mode2400_variants.txt.)
+constexpr uint32_t kPulseWeightBits = 0x3C01u; // f16 1 + 2^-10
+constexpr uint32_t kQuietWeightBits = 0xBFFFu; // f16 -2 (1 - 2^-11) = -1.9990234375: the step from -2 towards zero
 
 // overlap, in fifths of a sample, of the half-microsecond slot k of a frame that starts phi fifths into its first sample with
 // sample t of the window (oracle2400.c: overlap5 / slot_energy)
@@ -105,7 +114,7 @@ __device__ __forceinline__ BitWindow bit_window(const uint16_t* img16, uint32_t 
     BitWindow w;
     w.p = T - 5 * i0;
 #pragma unroll
-    for (int t = 0; t < 4; t++) w.s[t] = img16[a0 + 2 * (i0 + t)];
+    for (int t = 0; t < 4; t++) w.s[t] = img16[a0 + (uint32_t)(i0 + t)];
     return w;
 }
 __device__ __forceinline__ float corr_estimate(const BitWindow& w)
@@ -215,23 +224,81 @@ __device__ __forceinline__ void row_scan_add7(int (&v)[7])
 #undef ROW7
 }
 
+// Two samples' I, Q bytes (I0 Q0 I1 Q1) -> (s0 | s1 << 16): byte ^ 0x7F is 127 - byte as a signed 8-bit number (scan_common.hip.h, rows_to_s2);
+// v_perm_b32 sign-extends the odd bytes of its second operand (selectors 8 and 9), the even ones after a shift by one byte
+__device__ __forceinline__ uint32_t iq2_to_s2_linear(uint32_t x)
+{
+    const uint32_t z = x ^ 0x7F7F7F7Fu, u = z << 8;
+    return pair_to_s2(__builtin_amdgcn_perm(0u, u, 0x09030801u), __builtin_amdgcn_perm(0u, z, 0x09030801u));
+}
+
+// The A operand of the prefilter's matrix product: lane l = (row r = l & 31, half h = l >> 5) holds, for each of the four 16-sample steps kb
+// of a column's 64 samples, the weights of samples 16 kb + 8 h .. + 7 of the column (sample m of column c is sample 32 c - 8 + m of the chunk)
+// for the position its row stands for.
+// Row r of the product comes out in register i = (r & 3) + 4 (r >> 3) of lane half (r >> 2) & 1 (the instruction's result map); it is given
+// position v = 16 ((r >> 2) & 1) + 4 (r >> 3) + (r & 3) of the column, so that lane (c, h) ends up with positions 32 c + 16 h + i, i = 0 .. 15,
+// in register order: sixteen consecutive bits of the survivor map.
+// The weights are a table in device memory, 64 bytes a lane, fetched at the top of every chunk and dead after the product: kept in registers
+// across the chunk's sparse phases they were sixteen registers too many (a row of the prefetched window went to scratch and back).
+struct GateTable
+{
+    uint32_t w[64][16]; // [lane][4 kb + j]: f16 pair of samples 16 kb + 8 h + 2 j, + 1
+};
+constexpr GateTable make_gate_table()
+{
+    GateTable t{};
+    for (int lane = 0; lane < 64; lane++)
+    {
+        const int r = lane & 31, h = lane >> 5, v = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+        for (int kb = 0; kb < 4; kb++)
+            for (int j = 0; j < 8; j++)
+            {
+                const int      a = -kImgPad + 16 * kb + 8 * h + j - v; // the sample's offset from the row's position
+                const int      w = (a >= -1 && a <= 17) ? prefilter_weight(a) : 0;
+                const uint32_t b = w > 0 ? kPulseWeightBits : w < 0 ? kQuietWeightBits : 0u;
+                t.w[lane][4 * kb + (j >> 1)] |= b << (16 * (j & 1));
+            }
+    }
+    return t;
+}
+__device__ const GateTable kGateTable = make_gate_table();
+
+// (two conversions per register, the second into the upper half of the first one's result; left to itself the compiler converts into two
+// registers and packs them: three instructions)
+__device__ __forceinline__ uint32_t pair_to_f16(uint32_t x)
+{
+    uint32_t r;
+    asm("v_cvt_f16_u16_e32 %0, %1\n\t"
+        "v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1"
+        : "=&v"(r)
+        : "v"(x));
+    return r;
+}
+__device__ __forceinline__ h8_t halves_to_f16(uint4 x)
+{
+    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(h8_t, u4_t{pair_to_f16(x.x), pair_to_f16(x.y), pair_to_f16(x.z), pair_to_f16(x.w)});
+}
+
 __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t img[kImgDwords];
-    __shared__ uint16_t                              queue[kQueue24];
-    __shared__ uint8_t                               wlist[kQueue24]; // (a queue of 64 and a byte per winner: 10 208 bytes a wave, sixteen waves a CU)
+    __shared__ __attribute__((aligned(16))) uint16_t img16[kImgHalves];
+    __shared__ __attribute__((aligned(8))) uint16_t  gatemap[kChunk / 16]; // bit p of the map: position p passes the prefilter (64 x 64 bits)
+    __shared__ uint16_t                              gqueue[kQueue24];    // prefilter survivors of a pass (positions)
+    __shared__ uint16_t                              queue[kQueue24];     // gate survivors of a pass
+    __shared__ uint8_t                               wlist[kQueue24];
     __shared__ uint32_t                              score[kQueue24], pulse[kQueue24]; // per queue entry: best P << 3 | phase; pulse amplitude A
-    uint16_t* const                                  img16 = reinterpret_cast<uint16_t*>(img);
 
-    const int        lane = threadIdx.x;
+    const int lane = threadIdx.x;
     stamp(a.stamps, 0);
-    const LaneTables lt   = load_lane_tables(a.crc_tab, lane);
+    const LaneTables lt = load_lane_tables(a.crc_tab, lane);
     // preamble weights of this lane (see the candidate loop)
     const int tl = lane & 15, rw = lane >> 4;
     int       wpk = 0; // the five phases' weights of window sample tl, four bits each (signed, -5 .. 5)
     if (tl < 13)
         for (int k = 0; k < 5; k++) wpk |= ((int)kPreamble.p[k][tl] & 15) << (4 * k);
     if (blockIdx.x == 0 && lane < 2) total_overflow[lane] = 0; // {record total, overflow flag}: filled by the ordering pass that follows in-stream
+    if (lane < kImgPad) img16[lane] = 0; // the halves in front of the image: zero weights, but they go through the multiplier
 
     // persistent waves, chunk order and work counters as in scan1090_kernel (scan_common.hip.h)
     WorkRange wr = work_range(a);
@@ -245,30 +312,52 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
 
     for (;;)
     {
-    // ---------------- window -> s, the two halves of the chunk interleaved (rows j and j + 4; j = 4: row 4 again beside the halo row)
+    // the prefilter's weights: issued here (nothing else is in flight: the window these rows came from has landed), used behind the image build.
+    // The empty statement makes the address a new value every trip: a loop-invariant load would be hoisted and its registers stay live.
+    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+    const u4_t* wsrc = reinterpret_cast<const u4_t*>(kGateTable.w[lane]);
+    asm volatile("" : "+v"(wsrc));
+    const u4_t wq0 = wsrc[0], wq1 = wsrc[1], wq2 = wsrc[2], wq3 = wsrc[3];
+    // ---------------- window -> s: a lane's sixteen bytes of a row are eight consecutive samples, eight halves of the image
     __builtin_amdgcn_s_setprio(0);
     wave_lds_fence(); // readers of the previous chunk are done
 #pragma unroll
-    for (int jr = 0; jr <= kRows / 2; jr++)
+    for (int jr = 0; jr <= kRows; jr++)
     {
-        const uint4 x = raw.row[jr], y = raw.row[jr + kRows / 2];
-        uint32_t    t[8];
-        rows_to_s2(x.x, y.x, t[0], t[1]);
-        rows_to_s2(x.y, y.y, t[2], t[3]);
-        rows_to_s2(x.z, y.z, t[4], t[5]);
-        rows_to_s2(x.w, y.w, t[6], t[7]);
-        if (jr < kRows / 2 || lane < kHalo24 / 8)
-        {
-            uint4* dst = reinterpret_cast<uint4*>(&img[kImgBase + jr * kRowSamples + 8 * lane]);
-            dst[0]     = make_uint4(t[0], t[1], t[2], t[3]);
-            dst[1]     = make_uint4(t[4], t[5], t[6], t[7]);
-        }
-        // the dword in front of q = 0: low half = the sample before the chunk (0 at the start of a buffer), high half = s[2047]
-        if (jr == kRows / 2 - 1 && lane == 63) img16[2 * (kImgBase - 1) + 1] = (uint16_t)t[7];
+        const uint4 x = raw.row[jr];
+        if (jr < kRows || lane < kHalo24 / 8)
+            *reinterpret_cast<uint4*>(&img16[kImgPad + jr * kRowSamples + 8 * lane]) =
+                make_uint4(iq2_to_s2_linear(x.x), iq2_to_s2_linear(x.y), iq2_to_s2_linear(x.z), iq2_to_s2_linear(x.w));
     }
-    if (lane == 0) img16[2 * (kImgBase - 1)] = (uint16_t)iq1_to_s(raw.front & 0xFFu, raw.front >> 8);
+    // the sample before the chunk (0 at the start of a buffer: oracle2400_gate)
+    if (lane == 0) img16[kImgPad - 1] = (uint16_t)iq1_to_s(raw.front & 0xFFu, raw.front >> 8);
 
-    // ---------------- prefetch: the next chunk's loads fly while this chunk is processed
+    wave_lds_fence(); // the image is complete
+
+    // ---------------- prefilter on the matrix pipe (see the head of the file): 1024 positions per trip.  Lane (c, h) reads samples
+    // 16 kb + 8 h .. + 7 of column c (one ds_read_b128 per step; at a lane stride of 64 bytes they are four-way bank conflicted, which the
+    // LDS has room for) and converts them.
+    {
+        const uint4* col   = reinterpret_cast<const uint4*>(img16) + 4 * (lane & 31) + (lane >> 5);
+        const h8_t   gw[4] = {__builtin_bit_cast(h8_t, wq0), __builtin_bit_cast(h8_t, wq1), __builtin_bit_cast(h8_t, wq2), __builtin_bit_cast(h8_t, wq3)};
+#pragma unroll 1
+        for (int blk = 0; blk < kChunk / kGateBlock; blk++, col += 2 * kGateBlock / 16)
+        {
+            f16_t acc = {4.0f, 4.0f, 4.0f, 4.0f, 4.0f, 4.0f, 4.0f, 4.0f, 4.0f, 4.0f, 4.0f, 4.0f, 4.0f, 4.0f, 4.0f, 4.0f};
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(gw[kb], halves_to_f16(col[2 * kb]), acc, 0, 0, 0);
+            // acc >= 0: the position passes.  Sign bits of the sixteen results, register 15 first, so that register i ends at bit i
+            typedef uint32_t u16x_t __attribute__((ext_vector_type(16)));
+            const u16x_t     bits = __builtin_bit_cast(u16x_t, acc);
+            uint32_t         m    = 0;
+#pragma unroll
+            for (int i = 15; i >= 0; i--) m = __builtin_amdgcn_alignbit(m, bits[i], 31);
+            gatemap[(kGateBlock / 16) * blk + 2 * (lane & 31) + (lane >> 5)] = (uint16_t)~m;
+        }
+    }
+    // ---------------- prefetch: the next chunk's loads fly while the rest of this chunk is processed.  (Behind the prefilter, not in front of it:
+    // the matrix product wants its weights, its accumulators and the pieces it converts in registers at the same time as the window's 36
+    // would be; in front, the compiler parked a row of the window in scratch, i.e. waited for its load on the spot.)
     const uint32_t me = chunk, g0 = g.g0, npos = g.npos;
     // control traffic (the previous chunk's directory entry and sums, the ticket for the work item after `next`) in front of the loads
     publish(a, pend, lane);
@@ -277,74 +366,27 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     if (next != kNoChunk)
     {
         g = chunk_geom_of(a, next, kSpan24);
-        load_window<kHalo24>(g, lane, raw);
+        int pl = lane; // (a new value every trip: the loads' lane offsets are recomputed -- three instructions -- rather than kept in scratch)
+        asm volatile("" : "+v"(pl));
+        load_window<kHalo24>(g, pl, raw);
     }
     wave_lds_fence();
-
-    // ---------------- gate (oracle2400_gate), packed: 3 min(s0+s1, s2+s3, s8+s9, s10+s11+s12) > 2 (s-1 + s5+s6+s7 + s14+s15+s16+s17)
-    uint32_t surv32[2] = {0u, 0u};
-#pragma unroll
-    for (int b = 0; b < kHalfChunk / 512; b++)
-    {
-        // T[i] = dword q0 - 4 + i of the image, q0 = 512 b + 8 lane: sample a of position q0 + k is T[4 + k + a]
-        // eight 16-byte reads, written out: left to itself the compiler drops the three unused leading dwords and falls back to
-        // 13 misaligned 8-byte reads (lane stride 32 bytes: eight-way bank conflicts)
-        uint32_t       T[32];
-        const uint32_t addr = (uint32_t)(uintptr_t)&img[kImgBase + b * 512 + 8 * lane - 4];
-        uint4          v0, v1, v2, v3, v4, v5, v6, v7;
-        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
-                     "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
-                     : "v"(addr)
-                     : "memory");
-        T[0] = v0.x; T[1] = v0.y; T[2] = v0.z; T[3] = v0.w; T[4] = v1.x; T[5] = v1.y; T[6] = v1.z; T[7] = v1.w;
-        T[8] = v2.x; T[9] = v2.y; T[10] = v2.z; T[11] = v2.w; T[12] = v3.x; T[13] = v3.y; T[14] = v3.z; T[15] = v3.w;
-        T[16] = v4.x; T[17] = v4.y; T[18] = v4.z; T[19] = v4.w; T[20] = v5.x; T[21] = v5.y; T[22] = v5.z; T[23] = v5.w;
-        T[24] = v6.x; T[25] = v6.y; T[26] = v6.z; T[27] = v6.w; T[28] = v7.x; T[29] = v7.y; T[30] = v7.z; T[31] = v7.w;
-        uint32_t P2[28]; // saturating pair sums s_a + s_a+1 (P2[z .. z + 16] for z = 4 .. 11)
-#pragma unroll
-        for (int i = 4; i < 28; i++) P2[i] = pk_add_sat(T[i], T[i + 1]);
-        uint32_t acc = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-        {
-            const int      z  = 4 + k; // T index of s0
-            const uint32_t A  = P2[z], B = P2[z + 2], C = P2[z + 8], D = pk_add_sat(P2[z + 10], T[z + 12]);
-            uint32_t       q  = pk_add_sat(T[z - 1], P2[z + 5]);
-            q                 = pk_add_sat(q, T[z + 7]);
-            q                 = pk_add_sat(q, P2[z + 14]);
-            q                 = pk_add_sat(q, P2[z + 16]);
-            const uint32_t lo = pk_min_u(pk_min_u(A, B), pk_min_u(C, D));
-            uint32_t lo3; // 3 lo, saturating: one multiply-add instead of two additions
-            asm("v_pk_mad_u16 %0, %1, %2, 0 clamp" : "=v"(lo3) : "v"(lo), "s"(0x00030003u));
-            const uint32_t ok = pk_min_asm(pk_sub_sat(lo3, pk_add_sat(q, q)), 0x00010001u); // 1 per half where 3 lo > 2 q
-            const u16x2    wt = {(unsigned short)(1u << k), (unsigned short)(256u << k)};
-            acc               = __builtin_amdgcn_udot2(as_pk(ok), wt, acc, false);
-        }
-        if (b & 1) surv32[b >> 1] |= acc << 16;
-        else surv32[b >> 1] = acc;
-    }
-    uint64_t surv = (uint64_t)surv32[0] | ((uint64_t)surv32[1] << 32);
+    // a lane's 64 positions: 64 lane .. 64 lane + 63 (eight whole groups of 8: a run of gate survivors never leaves a lane)
+    uint64_t surv = *reinterpret_cast<const uint64_t*>(&gatemap[4 * lane]);
     // the rest of the chunk is short dependent chains: raised priority lets them through the vector-dense phases of the other waves (see
     // scan1090_kernel; 0.631 -> 0.621 ms per GiB here)
     __builtin_amdgcn_s_setprio(1);
     if (npos < (uint32_t)kChunk)
     {
-#pragma unroll
-        for (int m = 0; m < 64; m += 8)
-        {
-            const int nvalid = (int)npos - (kHalfChunk * ((m >> 3) & 1) + 512 * (m >> 4) + 8 * lane);
-            uint64_t  keep   = (nvalid >= 8) ? 0xFFull : (nvalid <= 0 ? 0ull : ((1ull << nvalid) - 1ull));
-            surv &= ~(0xFFull << m) | (keep << m);
-        }
+        const int nvalid = (int)npos - 64 * lane;
+        surv &= nvalid >= 64 ? ~0ull : (nvalid <= 0 ? 0ull : ((1ull << nvalid) - 1ull));
     }
 
-    // ---------------- candidates -> queue -> demodulation, kQueue24 per pass
+    // ---------------- prefilter survivors -> exact gate -> queue -> demodulation, kQueue24 prefilter survivors per pass
     if constexpr (diag::kParts == 1)
-    { // measurement build: image + gate only
+    { // measurement build: image + prefilter only
         Emit e  = begin_chunk(a, me);
-        e.count = (surv == 0x123456789ull) ? 1 : 0; // keeps the gate alive
+        e.count = (surv == 0x123456789ull) ? 1 : 0; // keeps the prefilter alive
         pend    = finish_chunk(me, e);
         if (next == kNoChunk) break;
         chunk = next;
@@ -368,19 +410,39 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
             last_lane = __builtin_ctzll(over);
             next_base = (uint32_t)__builtin_amdgcn_readlane((int)excl, last_lane);
         }
-        const uint32_t nq = next_base - base; // <= kQueue24; > 0 because a lane holds at most 64
+        const uint32_t ng = next_base - base; // <= kQueue24; > 0 because a lane holds at most 64
         if (excl >= base && lane < last_lane)
-        {
-            uint64_t sv  = surv;
+        { // the two 32-bit halves one after the other: find-first-set and clear-lowest stay 32-bit operations
             uint32_t idx = excl - base;
-            while (sv)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
             {
-                const int bit = __builtin_ctzll(sv);
-                sv &= sv - 1;
-                queue[idx++] = (uint16_t)(kHalfChunk * ((bit >> 3) & 1) + 512 * (bit >> 4) + 8 * lane + (bit & 7));
+                uint32_t sv = (uint32_t)(surv >> (32 * h));
+                while (sv)
+                {
+                    const uint32_t bit = (uint32_t)__builtin_ctz(sv);
+                    sv &= sv - 1u;
+                    gqueue[idx++] = (uint16_t)(64u * (uint32_t)lane + 32u * (uint32_t)h + bit);
+                }
             }
         }
         wave_lds_fence();
+        // ---- the exact gate (oracle2400_gate), a lane per prefilter survivor: every sum in 32 bits, the saturations of the specification
+        // reduce to "2 Q below 65535" (3 lo saturated exceeds 2 Q saturated only when 2 Q is not, and then 3 lo > 2 Q decides)
+        uint32_t nq;
+        {
+            const bool     in  = (uint32_t)lane < ng;
+            const uint32_t pos = in ? gqueue[lane] : 0u;
+            const uint16_t* w  = &img16[(uint32_t)kImgPad + pos]; // sample a of the position: w[a]
+            const uint32_t A = (uint32_t)w[0] + w[1], B = (uint32_t)w[2] + w[3], C = (uint32_t)w[8] + w[9], D = (uint32_t)w[10] + w[11] + w[12];
+            const uint32_t Q = (uint32_t)w[-1] + w[5] + w[6] + w[7] + w[14] + w[15] + w[16] + w[17];
+            const uint32_t lo3 = 3u * __builtin_elementwise_min(__builtin_elementwise_min(A, B), __builtin_elementwise_min(C, D));
+            const uint64_t okm = ballot(in && 2u * Q < 65535u && lo3 > 2u * Q);
+            if ((okm >> lane) & 1ull) queue[__builtin_popcountll(okm & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+            nq = (uint32_t)__builtin_popcountll(okm);
+        }
+        wave_lds_fence();
+        if constexpr (diag::kParts == 2) nq = nq == 0x12345678u ? 1u : 0u; // measurement build: + the exact gate
         // ---- preamble scores, four candidates per trip: row r of 16 lanes takes entry t + r, lane 16 r + i holds sample i of its window
         // (13 of them matter); five weighted row sums give P(phi), lane 15 of the row keeps the best (first of equals) and stores
         // best << 3 | phi, or 0 when the survivor does not qualify (P <= 0, or the pulse slots do not stand out of the ten: most gate
@@ -389,8 +451,8 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
         {
             const uint32_t q   = t + (uint32_t)rw;
             const uint32_t pos = queue[q < nq ? q : nq - 1];
-            const uint32_t a0  = 2u * (uint32_t)kImgBase + 2u * (pos & (uint32_t)(kHalfChunk - 1)) + (pos >> 11);
-            const int      m   = mag_of_s(img16[a0 + 2 * tl]);
+            const uint32_t a0  = (uint32_t)kImgPad + pos;
+            const int      m   = mag_of_s(img16[a0 + (uint32_t)tl]);
             // P(phi) for the five phases, m0 + .. + m11 and m12 - m0: seven sums over the row
             int v[7];
 #pragma unroll
@@ -414,9 +476,8 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
         // ---- one candidate per run: entry q stands for its run (gate survivors at consecutive positions inside one group of 8) when
         // its score is positive, larger than every earlier member's and not smaller than any later member's
         uint32_t nw = 0;
-        for (uint32_t r0 = 0; r0 < nq; r0 += 64)
         {
-            const uint32_t q   = r0 + (uint32_t)lane;
+            const uint32_t q   = (uint32_t)lane;
             const bool     in  = q < nq;
             const uint32_t pos = in ? queue[q] : 0u;
             const uint32_t sc  = in ? score[q] >> 3 : 0u;
@@ -435,12 +496,12 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
                 if (run && (score[q + k] >> 3) > sc) win = false, run = false;
             }
             const uint64_t wins = ballot(win);
-            if (win) wlist[nw + (uint32_t)__builtin_popcountll(wins & ((1ull << lane) - 1ull))] = (uint8_t)q;
-            nw += (uint32_t)__builtin_popcountll(wins);
+            if (win) wlist[(uint32_t)__builtin_popcountll(wins & ((1ull << lane) - 1ull))] = (uint8_t)q;
+            nw = (uint32_t)__builtin_popcountll(wins);
         }
         wave_lds_fence();
-        if constexpr (diag::kParts == 2)
-            if (nw != 0x12345678u) nw = 0; // measurement build: + queue, scores and run rule
+        if constexpr (diag::kParts == 3)
+            if (nw != 0x12345678u) nw = 0; // measurement build: + scores and run rule
         // ---- the candidates, one at a time with the whole wave
         for (uint32_t w = 0; w < nw; w++)
         {
@@ -448,12 +509,12 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
             const uint32_t pos      = (uint32_t)__builtin_amdgcn_readfirstlane((int)queue[q]);
             const uint32_t packed   = (uint32_t)__builtin_amdgcn_readfirstlane((int)score[q]);
             const int      phi_star = (int)(packed & 7u);
-            const uint32_t a0       = 2u * (uint32_t)kImgBase + 2u * (pos & (uint32_t)(kHalfChunk - 1)) + (pos >> 11); // half of sample t = 0
+            const uint32_t a0       = (uint32_t)kImgPad + pos; // half of sample t = 0
             const int      amp      = (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)pulse[q]);
             // (Looking at the five DF bits first and slicing the rest only for a DF that can be accepted saved 28 vector instructions per chunk
             // in the round-2 form and cost as much in LDS round trips: dropped.)
             if (slice_and_emit(img16, a0, lane, lt, e, g0 + pos, phi_star, amp)) continue;
-            if constexpr (diag::kParts == 3) continue; // measurement build: + the first slice of the candidates
+            if constexpr (diag::kParts == 4) continue; // measurement build: + the first slice of the candidates
             if (phi_star + 1 <= 4 && slice_and_emit(img16, a0, lane, lt, e, g0 + pos, phi_star + 1, amp)) continue;
             if (phi_star - 1 >= 0) (void)slice_and_emit(img16, a0, lane, lt, e, g0 + pos, phi_star - 1, amp);
         }

@@ -383,7 +383,8 @@ __device__ __forceinline__ void load_window(const ChunkGeom& g, int lane, RawWin
         typedef const __attribute__((address_space(1))) u32x2_t* gvec2_t;
         uint64_t b0 = reinterpret_cast<uint64_t>(g.buf) + 2ull * g.g0, b1 = b0 + 4096u, b2 = b0 + 2u * (uint32_t)kChunk;
         asm("" : "+s"(b0), "+s"(b1), "+s"(b2));
-        const uint32_t off = 16u * (uint32_t)lane, off_halo = 16u * ((uint32_t)lane % (uint32_t)(HALO / 8));
+        static_assert(HALO / 8 >= kLanes / 2, "one subtraction folds a lane beyond the halo back into it");
+        const uint32_t off = 16u * (uint32_t)lane, off_halo = 16u * (uint32_t)(lane >= HALO / 8 ? lane - HALO / 8 : lane); // (lane modulo the halo's lanes)
 #pragma unroll
         for (int k = 0; k < kRows + (SPLIT ? 0 : 1); k++)
         {

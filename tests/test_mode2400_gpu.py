@@ -32,6 +32,21 @@ def test_records_equal_the_specification(scanner24, over):
     H.assert_records_equal(scanner24.scan(iq20, BB), O.expected_records2400(iq20, BB, dtype=A.RECORD_DTYPE))
 
 
+def test_random_generator_settings_against_the_specification(scanner24):
+    """The gate runs in two steps on the GPU: a necessary condition on the matrix cores (f16 products of the converted powers, weights that lean
+    the safe way, scan2400.hip) and the exact gate for its survivors.  A position the first step wrongly dropped would be a missing record, so the
+    settings below put many positions near the gate's threshold at every scale: signals up to full scale (powers up to 32767, where an f16 holds
+    the power to 1 part in 2048), noise up to +-90, dense and sparse frames."""
+    rng = np.random.default_rng(24005)
+    for k in range(48):
+        big = k % 3 == 0
+        cfg = synth.default_cfg(noise_amp=int(rng.integers(0, 91 if big else 40)), mean_spacing=int(rng.choice([0, 250, 600, 2000, 20000])),
+                                amp_lo=int(rng.integers(90, 128) if big else rng.integers(3, 100)), amp_hi=128 if big else int(rng.integers(100, 129)),
+                                pct_df17=int(rng.integers(0, 60)), pct_df11=int(rng.integers(0, 40)), pct_bitflip=int(rng.integers(0, 100)))
+        iq, _ = synth.fill_range(int(rng.integers(0, 10**6)), 2, cfg=cfg, rate_x10=24)
+        H.assert_records_equal(scanner24.scan(iq, BB), O.expected_records2400(iq, BB, dtype=A.RECORD_DTYPE))
+
+
 @pytest.mark.parametrize("nbytes", [0, 2, 584, 586, 588, 600, 8192 + 586, 8192 + 600, 3 * 8192 + 590, 262144 - 2, 262144 + 6, 2 * 262144 + 1000])
 def test_ragged_single_buffer(scanner24, nbytes):
     base, _ = synth.fill_range(7, 3, cfg=synth.default_cfg(mean_spacing=400), rate_x10=24)

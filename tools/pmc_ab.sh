@@ -8,9 +8,10 @@ for name in "$@"; do
     if [ $pass = 1 ]; then ctr="SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA";
     elif [ $pass = 3 ]; then ctr="FETCH_SIZE";
     elif [ $pass = 4 ]; then ctr="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum";
+    elif [ $pass = 5 ]; then ctr="SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES";
     else ctr="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD"; fi
     out=$root/gpurun_out/pmc_ab/$name.$pass; rm -rf $out; mkdir -p $out
-    (cd /tmp && ADSB_AMD_LIB=$root/ab_libs/$name.so rocprofv3 --pmc $ctr --output-format csv -d $out/p -- python3 $root/bench.py --steps 3 --warmup 1 --cpu-buffers 0 --serial --no-extras $AB_BENCH_ARGS > $out/log 2>&1)
+    (cd /tmp && ADSB_AMD_LIB=$root/${AB_DIR:-ab_libs}/$name.so rocprofv3 --pmc $ctr --output-format csv -d $out/p -- python3 $root/bench.py --steps 3 --warmup 1 --cpu-buffers 0 --serial --no-extras $AB_BENCH_ARGS > $out/log 2>&1)
   done
 done
 python3 - "$@" <<'PY'
