@@ -93,7 +93,52 @@ constexpr PreambleWeights make_preamble_weights()
         }
     return w;
 }
-__constant__ PreambleWeights kPreamble = make_preamble_weights();
+constexpr PreambleWeights kPreambleHost = make_preamble_weights();
+
+// The preamble scores as a matrix product (round 5).  Seven weighted sums of a gate survivor's 13 window magnitudes are wanted -- P(phi) for the
+// five phases, m0 + .. + m11 and m12 - m0 -- exactly, for every survivor.  The magnitudes (16 bits) go to LDS as bytes, survivor by survivor,
+// and v_mfma_i32_32x32x32_i8 forms all sums of sixteen survivors at once: column = survivor, K = the 32 bytes of its 16 halves (13 magnitudes,
+// one constant, two unused), rows = (sum, byte plane).  The matrix cores multiply SIGNED bytes, so every byte is stored XOR 0x80 (= minus 128);
+// half 13 holds the constant bytes 0x80 0x80 (minus 128 each) with weight minus (sum of the row's weights), which takes the bias out again:
+// row (f, low) is exactly sum w_f[t] low(m_t), row (f, high) exactly sum w_f[t] high(m_t), and the sum is 256 high + low.
+// A lane of the result holds rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): the low-byte row of sum f is given register f, its high-byte row
+// register 8 + f, both in the lower lane half, so that lane n (n < 16) ends up with everything about survivor n in its own registers.
+// Replaces four survivors per trip with one magnitude per lane, seven DPP row sums and a best-of-five per row of sixteen lanes.
+struct ScoreTable
+{
+    uint32_t w[64][4]; // [lane = row | half << 5][dword of its 16 K bytes]
+};
+constexpr int score_weight(int f, int t)
+{ // weight of half t of a survivor's row in sum f (t = 13: the constant half)
+    int w = 0, sum = 0;
+    for (int u = 0; u < 13; u++)
+    {
+        const int x = f < 5 ? kPreambleHost.p[f][u] : f == 5 ? (u < 12 ? 1 : 0) : (u == 12 ? 1 : u == 0 ? -1 : 0);
+        sum += x;
+        if (u == t) w = x;
+    }
+    return t < 13 ? w : t == 13 ? -sum : 0;
+}
+constexpr ScoreTable make_score_table()
+{
+    ScoreTable t{};
+    for (int lane = 0; lane < 64; lane++)
+    {
+        const int r = lane & 31, h = lane >> 5;
+        if (r & 4) continue;                       // rows of the upper lane half's registers: unused
+        const int reg = (r & 3) + 4 * (r >> 3);     // the register this row comes out in (lower lane half)
+        const int f = reg & 7, plane = reg >> 3;    // sum, byte plane (0 low, 1 high)
+        if (f >= 7) continue;
+        for (int b = 0; b < 16; b++)
+        {
+            const int k = 16 * h + b, half = k >> 1;
+            if ((k & 1) != plane) continue;
+            t.w[lane][b >> 2] |= ((uint32_t)score_weight(f, half) & 0xFFu) << (8 * (b & 3));
+        }
+    }
+    return t;
+}
+__device__ const ScoreTable kScoreTable = make_score_table();
 
 // Correlation of bit b at phase phi (oracle2400.c: c_b): the four samples of its window, weights of its own sub-sample position p,
 // 5 i0 + p = phi + 96 + 12 b: {5-p, 2p-3, -min(2+p,5), -(p==4)}.  Two forms.  The float one works on estimates of the magnitudes (each within
@@ -192,8 +237,14 @@ __device__ __forceinline__ bool slice_and_emit(const uint16_t* img16, uint32_t a
         if (syn != 0)
         {
             if (weak > 2) return false;
-            const uint64_t ma = is_long ? ballot(syn == lt.syn_a) : ballot(lane < 56 && syn == lt.syn_s);
-            const uint64_t mb = is_long ? ballot(has_b && syn == lt.syn_b) : 0ull;
+            // the syndrome of flipping a bit: its parity-table entry for a data bit, the bit itself inside the parity field (load_lane_tables'
+            // syn_*; worked out here, in the one frame in ten that needs a repair, from a lane number the compiler cannot see through: as three
+            // more lane constants kept for the whole launch they cost registers the prefetched window needs)
+            int ol = lane;
+            asm volatile("" : "+v"(ol));
+            const uint32_t syn_b = ol < 24 ? lt.crc_b : 1u << ((47 - ol) & 31), syn_s = ol < 32 ? lt.crc_s : 1u << ((55 - ol) & 31);
+            const uint64_t ma = is_long ? ballot(syn == lt.crc_a) : ballot(ol < 56 && syn == syn_s);
+            const uint64_t mb = is_long ? ballot(ol < 48 && syn == syn_b) : 0ull;
             if (ma) errorbit = __builtin_ctzll(ma);
             else if (mb) errorbit = 64 + __builtin_ctzll(mb);
             else return false;
@@ -204,24 +255,6 @@ __device__ __forceinline__ bool slice_and_emit(const uint16_t* img16, uint32_t a
     if (weak > 4) return false;
     emit_raw(e, lane, j, ba, bb, df, nbits, -1, ADSB_AMD_F_NEEDS_ICAO, syn, (uint32_t)phi);
     return true;
-}
-
-// inclusive sums inside each row of 16 lanes (lane 15 of the row ends with the row's total); the additions carry the DPP modifier
-// themselves (see wave_incl_scan_add, scan_common.hip.h): four instructions per sum.  Seven sums at once, step by step across the seven: the
-// two wait states a DPP read needs after the write of its source are filled by the other chains' additions instead of by s_nops
-__device__ __forceinline__ void row_scan_add7(int (&v)[7])
-{
-#define ROW7(step)                                                                                          \
-    "v_add_u32_dpp %0, %0, %0 row_shr:" #step " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                 \
-    "v_add_u32_dpp %1, %1, %1 row_shr:" #step " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                 \
-    "v_add_u32_dpp %2, %2, %2 row_shr:" #step " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                 \
-    "v_add_u32_dpp %3, %3, %3 row_shr:" #step " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                 \
-    "v_add_u32_dpp %4, %4, %4 row_shr:" #step " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                 \
-    "v_add_u32_dpp %5, %5, %5 row_shr:" #step " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                 \
-    "v_add_u32_dpp %6, %6, %6 row_shr:" #step " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-    asm("s_nop 1\n\t" ROW7(1) ROW7(2) ROW7(4) ROW7(8) "s_nop 1"
-        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]));
-#undef ROW7
 }
 
 // Two samples' I, Q bytes (I0 Q0 I1 Q1) -> (s0 | s1 << 16): byte ^ 0x7F is 127 - byte as a signed 8-bit number (scan_common.hip.h, rows_to_s2);
@@ -283,20 +316,21 @@ __device__ __forceinline__ h8_t halves_to_f16(uint4 x)
 __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow)
 {
     __shared__ __attribute__((aligned(16))) uint16_t img16[kImgHalves];
-    __shared__ __attribute__((aligned(8))) uint16_t  gatemap[kChunk / 16]; // bit p of the map: position p passes the prefilter (64 x 64 bits)
+    __shared__ __attribute__((aligned(16))) uint16_t gatemap[kChunk / 16]; // bit p of the map: position p passes the prefilter (64 x 64 bits)
     __shared__ uint16_t                              gqueue[kQueue24];    // prefilter survivors of a pass (positions)
     __shared__ uint16_t                              queue[kQueue24];     // gate survivors of a pass
     __shared__ uint8_t                               wlist[kQueue24];
     __shared__ uint32_t                              score[kQueue24], pulse[kQueue24]; // per queue entry: best P << 3 | phase; pulse amplitude A
 
+    uint16_t* const scorebuf = gatemap; // sixteen survivors x 16 halves: the map is dead once every lane has read its 64 bits (see the scores)
+    static_assert(sizeof(gatemap) >= 16 * 16 * sizeof(uint16_t), "the score buffer fits where the survivor map was");
+
     const int lane = threadIdx.x;
     stamp(a.stamps, 0);
     const LaneTables lt = load_lane_tables(a.crc_tab, lane);
-    // preamble weights of this lane (see the candidate loop)
-    const int tl = lane & 15, rw = lane >> 4;
-    int       wpk = 0; // the five phases' weights of window sample tl, four bits each (signed, -5 .. 5)
-    if (tl < 13)
-        for (int k = 0; k < 5; k++) wpk |= ((int)kPreamble.p[k][tl] & 15) << (4 * k);
+    typedef int sw_t __attribute__((ext_vector_type(4)));
+    const sw_t score_w = *reinterpret_cast<const sw_t*>(kScoreTable.w[lane]); // the scores' weights (A operand), four registers for the whole launch
+    const int tl = lane & 15, rw = lane >> 4; // scoring: row rw of 16 lanes takes a survivor, lane tl of the row its window sample tl
     if (blockIdx.x == 0 && lane < 2) total_overflow[lane] = 0; // {record total, overflow flag}: filled by the ordering pass that follows in-stream
     if (lane < kImgPad) img16[lane] = 0; // the halves in front of the image: zero weights, but they go through the multiplier
 
@@ -314,10 +348,14 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     {
     // the prefilter's weights: issued here (nothing else is in flight: the window these rows came from has landed), used behind the image build.
     // The empty statement makes the address a new value every trip: a loop-invariant load would be hoisted and its registers stay live.
+    // (global loads, said explicitly: through a generic pointer they would be flat loads, which may return out of order, and the wait for
+    // the window's rows below would become a wait for these as well)
     typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
-    const u4_t* wsrc = reinterpret_cast<const u4_t*>(kGateTable.w[lane]);
-    asm volatile("" : "+v"(wsrc));
-    const u4_t wq0 = wsrc[0], wq1 = wsrc[1], wq2 = wsrc[2], wq3 = wsrc[3];
+    typedef const __attribute__((address_space(1))) u4_t* gw_ptr_t;
+    uint64_t waddr = reinterpret_cast<uint64_t>(&kGateTable.w[lane][0]);
+    asm volatile("" : "+v"(waddr));
+    const gw_ptr_t wsrc = reinterpret_cast<gw_ptr_t>(waddr);
+    const u4_t     wq0 = wsrc[0], wq1 = wsrc[1], wq2 = wsrc[2], wq3 = wsrc[3];
     // ---------------- window -> s: a lane's sixteen bytes of a row are eight consecutive samples, eight halves of the image
     __builtin_amdgcn_s_setprio(0);
     wave_lds_fence(); // readers of the previous chunk are done
@@ -332,6 +370,23 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     // the sample before the chunk (0 at the start of a buffer: oracle2400_gate)
     if (lane == 0) img16[kImgPad - 1] = (uint16_t)iq1_to_s(raw.front & 0xFFu, raw.front >> 8);
 
+    // (the weights, fetched at the top of the trip, are claimed here: left to the product, the compiler's wait for them would sit behind the
+    // prefetch, and where the paths of load_window meet it counts the loads of the shortest one -- a wait for most of the window)
+    asm volatile("" ::"v"(wq0), "v"(wq1), "v"(wq2), "v"(wq3));
+    // ---------------- prefetch: the next chunk's loads fly while this chunk is processed (the whole of it: issued behind the prefilter instead, the
+    // window had not landed when the next trip wanted it -- the sparse phases that were left to cover the loads are too short)
+    const uint32_t me = chunk, g0 = g.g0, npos = g.npos;
+    // control traffic (the previous chunk's directory entry and sums, the ticket for the work item after `next`) in front of the loads
+    publish(a, pend, lane);
+    uint32_t ticket = 0;
+    if (next != kNoChunk) ticket = grab_issue(a, wr, lane);
+    if (next != kNoChunk)
+    {
+        g = chunk_geom_of(a, next, kSpan24);
+        int pl = lane; // (a new value every trip: the loads' lane offsets are recomputed -- three instructions -- rather than kept in scratch)
+        asm volatile("" : "+v"(pl));
+        load_window<kHalo24>(g, pl, raw);
+    }
     wave_lds_fence(); // the image is complete
 
     // ---------------- prefilter on the matrix pipe (see the head of the file): 1024 positions per trip.  Lane (c, h) reads samples
@@ -354,21 +409,6 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
             for (int i = 15; i >= 0; i--) m = __builtin_amdgcn_alignbit(m, bits[i], 31);
             gatemap[(kGateBlock / 16) * blk + 2 * (lane & 31) + (lane >> 5)] = (uint16_t)~m;
         }
-    }
-    // ---------------- prefetch: the next chunk's loads fly while the rest of this chunk is processed.  (Behind the prefilter, not in front of it:
-    // the matrix product wants its weights, its accumulators and the pieces it converts in registers at the same time as the window's 36
-    // would be; in front, the compiler parked a row of the window in scratch, i.e. waited for its load on the spot.)
-    const uint32_t me = chunk, g0 = g.g0, npos = g.npos;
-    // control traffic (the previous chunk's directory entry and sums, the ticket for the work item after `next`) in front of the loads
-    publish(a, pend, lane);
-    uint32_t ticket = 0;
-    if (next != kNoChunk) ticket = grab_issue(a, wr, lane);
-    if (next != kNoChunk)
-    {
-        g = chunk_geom_of(a, next, kSpan24);
-        int pl = lane; // (a new value every trip: the loads' lane offsets are recomputed -- three instructions -- rather than kept in scratch)
-        asm volatile("" : "+v"(pl));
-        load_window<kHalo24>(g, pl, raw);
     }
     wave_lds_fence();
     // a lane's 64 positions: 64 lane .. 64 lane + 63 (eight whole groups of 8: a run of gate survivors never leaves a lane)
@@ -443,36 +483,42 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
         }
         wave_lds_fence();
         if constexpr (diag::kParts == 2) nq = nq == 0x12345678u ? 1u : 0u; // measurement build: + the exact gate
-        // ---- preamble scores, four candidates per trip: row r of 16 lanes takes entry t + r, lane 16 r + i holds sample i of its window
-        // (13 of them matter); five weighted row sums give P(phi), lane 15 of the row keeps the best (first of equals) and stores
-        // best << 3 | phi, or 0 when the survivor does not qualify (P <= 0, or the pulse slots do not stand out of the ten: most gate
-        // survivors of noise).
-        for (uint32_t t = 0; t < nq; t += 4)
+        // ---- preamble scores, sixteen survivors per matrix product (see kScoreTable).  First the magnitudes, four survivors per trip: row rw of 16
+        // lanes takes entry t + rw, lane tl of the row the exact magnitude of its window sample tl, and stores it, bytes XOR 0x80, as half tl of
+        // the survivor's 32 bytes (half 13: the constant, halves 14 and 15 carry no weight).  The buffer lives where the survivor map was.
+        for (uint32_t q0 = 0; q0 < nq; q0 += 16)
         {
-            const uint32_t q   = t + (uint32_t)rw;
-            const uint32_t pos = queue[q < nq ? q : nq - 1];
-            const uint32_t a0  = (uint32_t)kImgPad + pos;
-            const int      m   = mag_of_s(img16[a0 + (uint32_t)tl]);
-            // P(phi) for the five phases, m0 + .. + m11 and m12 - m0: seven sums over the row
+            const uint32_t nhere = nq - q0 < 16u ? nq - q0 : 16u;
+            for (uint32_t t = 0; t < nhere; t += 4)
+            {
+                const uint32_t q   = q0 + t + (uint32_t)rw;
+                const uint32_t pos = queue[q < nq ? q : nq - 1];
+                const uint32_t m   = (uint32_t)mag_of_s(img16[(uint32_t)kImgPad + pos + (uint32_t)tl]);
+                scorebuf[16u * (t + (uint32_t)rw) + (uint32_t)tl] = (uint16_t)(tl < 13 ? m ^ 0x8080u : tl == 13 ? 0x8080u : 0u);
+            }
+            wave_lds_fence();
+            // lane (n, h): bytes 16 h .. 16 h + 15 of survivor n & 15 (the upper sixteen columns repeat the lower ones; nobody reads their results)
+            typedef int v4i_t __attribute__((ext_vector_type(4)));
+            typedef int v16i_t __attribute__((ext_vector_type(16)));
+            const uint4  bq  = *reinterpret_cast<const uint4*>(&scorebuf[16 * (lane & 15) + 8 * (lane >> 5)]);
+            const v16i_t acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(score_w, v4i_t{(int)bq.x, (int)bq.y, (int)bq.z, (int)bq.w},
+                                                                     v16i_t{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
             int v[7];
 #pragma unroll
-            for (int k = 0; k < 5; k++) v[k] = __builtin_amdgcn_sbfe(wpk, 4 * k, 4) * m;
-            v[5] = tl < 12 ? m : 0, v[6] = tl == 12 ? m : tl == 0 ? -m : 0;
-            row_scan_add7(v);
+            for (int k = 0; k < 7; k++) v[k] = (int)(((uint32_t)acc[8 + k] << 8) + (uint32_t)acc[k]);
             int best = v[0], phi = 0;
 #pragma unroll
             for (int k = 1; k < 5; k++)
                 if (v[k] > best) best = v[k], phi = k;
             // qualifies (oracle2400.c): P > 0 and 8 P >= T(phi) = 5 (m0 + .. + m11) + phi (m12 - m0), what the ten slots hold
-            const int s12 = v[5], d12 = v[6];
-            const int total = 5 * s12 + phi * d12;
-            if (tl == 15 && q < nq)
+            const int total = 5 * v[5] + phi * v[6];
+            if ((uint32_t)lane < nhere)
             {
-                score[q] = (best > 0 && 8 * best >= total) ? ((uint32_t)best << 3) | (uint32_t)phi : 0u;
-                pulse[q] = (uint32_t)(((best + total) >> 1) / 24); // pulse - quiet = P and pulse + quiet = T: A = pulse / 24 (four slots of six fifths)
+                score[q0 + (uint32_t)lane] = (best > 0 && 8 * best >= total) ? ((uint32_t)best << 3) | (uint32_t)phi : 0u;
+                pulse[q0 + (uint32_t)lane] = (uint32_t)(((best + total) >> 1) / 24); // pulse - quiet = P and pulse + quiet = T: A = pulse / 24 (four slots of six fifths)
             }
+            wave_lds_fence(); // the next sixteen overwrite the buffer
         }
-        wave_lds_fence();
         // ---- one candidate per run: entry q stands for its run (gate survivors at consecutive positions inside one group of 8) when
         // its score is positive, larger than every earlier member's and not smaller than any later member's
         uint32_t nw = 0;
