@@ -315,10 +315,48 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
     uint64_t   ba = 0, bb = 0;
     uint32_t   df = 0, nbits = 0;
     bool       stateless = false;
+    // exact magnitudes of the first 64 bits' samples: the prelude below needs five of them, and whoever needs exact values later has these
+    x.loA = mag_of_s(sLoA), x.hiA = mag_of_s(sHiA);
     if (!pass1_done)
     {
+        // ---------------- prelude (round 5): can this candidate yield a record at all?  A record needs a DF the reference can accept (11 / 17, or an
+        // AP-type one) on pass 1 or on the retry, and the DF is the first five sliced bits.  Those are worked out here exactly, on the scalar unit,
+        // from ten magnitudes -- pass 1 (:830-853: bit 0 by comparison, a later bit copies its predecessor when |lo - hi| < 256), then, if pass 1
+        // cannot be accepted, the retry: none unless the preamble is out of phase (:814-826 -- then the retry slices the same window again), else
+        // ApplyPhaseCorrection's chain over bits 0 .. 4 (:720-736: the first sample of bit k + 1 becomes (x 5) / 4 or (x 4) / 5, 16 bits wide, by
+        // whether the already rescaled first sample of bit k exceeds its second).  Neither DF acceptable: nothing can come of the candidate
+        // whatever its energy gate says (:870-881 only decides between "dead" and "retry"), and the estimates, both energy sums, the 112-bit
+        // slicing, parity and the whole retry are skipped.  At noise +-20 that is one candidate in five (profiles/r05_sensitivity.txt).
+        int lo5[5], hi5[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) lo5[k] = __builtin_amdgcn_readlane(x.loA, k), hi5[k] = __builtin_amdgcn_readlane(x.hiA, k);
+        uint32_t df1 = 0, prev = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+        {
+            const bool     decided = k == 0 || abs(lo5[k] - hi5[k]) >= 256;
+            const uint32_t bit     = decided ? (uint32_t)(lo5[k] > hi5[k]) : prev;
+            df1 = (df1 << 1) | bit, prev = bit;
+        }
+        if (!(df1 == 11u || df1 == 17u || df_is_ap(df1)))
+        {
+            if (j == 0 || !preamble_out_of_phase(tile, lane, w, front)) return; // the retry would spell the same DF
+            uint32_t df2 = 0;
+            int      lo2 = lo5[0]; // the (rescaled) first sample of the bit at hand
+            prev         = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+            {
+                const bool     first_larger = lo2 > hi5[k];
+                const bool     decided      = k == 0 || abs(lo2 - hi5[k]) >= 256;
+                const uint32_t bit          = decided ? (uint32_t)first_larger : prev;
+                df2 = (df2 << 1) | bit, prev = bit;
+                if (k < 4) lo2 = first_larger ? (int)(uint16_t)((lo5[k + 1] * 5) / 4) : (int)(uint16_t)((lo5[k + 1] * 4) / 5);
+            }
+            if (!(df2 == 11u || df2 == 17u || df_is_ap(df2))) return;
+        }
         // ---------------- pass 1 on estimates
-        const float fA = __builtin_fabsf(mag_estimate(sLoA) - mag_estimate(sHiA));
+        const float fA = (float)abs(x.loA - x.hiA); // (exact since the prelude: never inside the margins below)
         const float fB = has_b ? __builtin_fabsf(mag_estimate(sLoB) - mag_estimate(sHiB)) : 0.0f;
         const float lo_edge = 256.0f - 2.0f * kEstErr, hi_edge = 256.0f + 2.0f * kEstErr;
         bool        need_exact = false;
@@ -333,13 +371,13 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
         }
         else
         {
-            const bool unsure = (lane != 0 && fA > lo_edge && fA < hi_edge) || (has_b && fB > lo_edge && fB < hi_edge);
+            const bool unsure = has_b && fB > lo_edge && fB < hi_edge; // (the first 64 bits' differences are exact)
             need_exact        = ballot(unsure) != 0;
             if (!need_exact)
             {
                 const uint32_t iA = (uint32_t)(fA + 0.5f), iB = (uint32_t)(fB + 0.5f);
                 const uint32_t e56 = wave_sum(lane < 56 ? iA : 0u), erest = wave_sum((lane >= 56 ? iA : 0u) + iB);
-                slice_resolve(lane, has_b, lane == 0 || fA >= hi_edge, valA, fB >= hi_edge, valB, &ba, &bb);
+                slice_resolve(lane, has_b, lane == 0 || fA >= 256.0f, valA, fB >= hi_edge, valB, &ba, &bb);
                 df    = (uint32_t)(__builtin_bitreverse64(ba) >> 59);
                 nbits = df_is_long(df) ? 112u : 56u;
                 // each |lo-hi| estimate is within 2*kEstErr + 0.5 of the true integer, so is the average
@@ -350,7 +388,7 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
         }
         if (need_exact)
         {
-            x.loA = mag_of_s(sLoA); x.hiA = mag_of_s(sHiA); x.loB = mag_of_s(sLoB); x.hiB = mag_of_s(sHiB);
+            x.loB = mag_of_s(sLoB); x.hiB = mag_of_s(sHiB);
             have_exact   = true;
             const int dA = abs(x.loA - x.hiA), dB = has_b ? abs(x.loB - x.hiB) : 0;
             sum56        = wave_sum(lane < 56 ? (uint32_t)dA : 0u);
@@ -368,7 +406,7 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
     }
     if (!have_exact)
     {
-        x.loA = mag_of_s(sLoA); x.hiA = mag_of_s(sHiA); x.loB = mag_of_s(sLoB); x.hiB = mag_of_s(sHiB);
+        x.loB = mag_of_s(sLoB); x.hiB = mag_of_s(sHiB);
         const int dA = abs(x.loA - x.hiA), dB = has_b ? abs(x.loB - x.hiB) : 0;
         sum56        = wave_sum(lane < 56 ? (uint32_t)dA : 0u);
         sumrest      = wave_sum((lane >= 56 ? (uint32_t)dA : 0u) + (uint32_t)dB);

@@ -440,8 +440,14 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     // A pass takes whole lanes (a lane's survivors of one 8-position group are consecutive queue entries in ascending position, so
     // a run never straddles two passes) until kQueue24 entries are full.
     const uint32_t excl = incl - mine;
+    // The prefilter's survivors go through the exact gate kQueue24 at a time; what passes collects in `queue` (whole groups of 8 positions:
+    // a pass takes whole lanes) and is worked on -- scores, run rule, slicing -- once a further pass's survivors do not fit any more (that pass
+    // is then simply run again for the next round), or at the end: once per chunk unless frames stand back to back.
     for (uint32_t base = 0; base < n1;)
     {
+        uint32_t nq = 0;
+        do
+        {
         const uint64_t over = ballot(excl >= base && incl > base + (uint32_t)kQueue24);
         uint32_t       next_base = n1;
         int            last_lane = 64; // lanes base-lane .. last_lane - 1 are in
@@ -469,19 +475,22 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
         wave_lds_fence();
         // ---- the exact gate (oracle2400_gate), a lane per prefilter survivor: every sum in 32 bits, the saturations of the specification
         // reduce to "2 Q below 65535" (3 lo saturated exceeds 2 Q saturated only when 2 Q is not, and then 3 lo > 2 Q decides)
-        uint32_t nq;
         {
             const bool     in  = (uint32_t)lane < ng;
-            const uint32_t pos = in ? gqueue[lane] : 0u;
-            const uint16_t* w  = &img16[(uint32_t)kImgPad + pos]; // sample a of the position: w[a]
+            const uint32_t pos_in = in ? gqueue[lane] : 0u;
+            const uint16_t* w  = &img16[(uint32_t)kImgPad + pos_in]; // sample a of the position: w[a]
             const uint32_t A = (uint32_t)w[0] + w[1], B = (uint32_t)w[2] + w[3], C = (uint32_t)w[8] + w[9], D = (uint32_t)w[10] + w[11] + w[12];
             const uint32_t Q = (uint32_t)w[-1] + w[5] + w[6] + w[7] + w[14] + w[15] + w[16] + w[17];
             const uint32_t lo3 = 3u * __builtin_elementwise_min(__builtin_elementwise_min(A, B), __builtin_elementwise_min(C, D));
-            const uint64_t okm = ballot(in && 2u * Q < 65535u && lo3 > 2u * Q);
-            if ((okm >> lane) & 1ull) queue[__builtin_popcountll(okm & ((1ull << lane) - 1ull))] = (uint16_t)pos;
-            nq = (uint32_t)__builtin_popcountll(okm);
+            const uint64_t okm   = ballot(in && 2u * Q < 65535u && lo3 > 2u * Q);
+            const uint32_t npass = (uint32_t)__builtin_popcountll(okm);
+            if (nq != 0 && nq + npass > (uint32_t)kQueue24) break; // no room: the queue is worked on first, this pass comes again
+            if ((okm >> lane) & 1ull) queue[nq + (uint32_t)__builtin_popcountll(okm & ((1ull << lane) - 1ull))] = (uint16_t)pos_in;
+            nq += npass;
+            base = next_base;
         }
         wave_lds_fence();
+        } while (base < n1);
         if constexpr (diag::kParts == 2) nq = nq == 0x12345678u ? 1u : 0u; // measurement build: + the exact gate
         // ---- preamble scores, sixteen survivors per matrix product (see kScoreTable).  First the magnitudes, four survivors per trip: row rw of 16
         // lanes takes entry t + rw, lane tl of the row the exact magnitude of its window sample tl, and stores it, bytes XOR 0x80, as half tl of
@@ -565,7 +574,6 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
             if (phi_star - 1 >= 0) (void)slice_and_emit(img16, a0, lane, lt, e, g0 + pos, phi_star - 1, amp);
         }
         wave_lds_fence();
-        base = next_base;
     }
     pend = finish_chunk(me, e);
 
