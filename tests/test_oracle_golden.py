@@ -108,6 +108,72 @@ def test_checksum_table_known_entries():
             syn.add(s)
 
 
+LIT = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_literals.json")))
+
+
+def test_every_literal_of_the_reference_checksum_table():
+    """All 112 entries the reference spells out (ADSB1090.cpp:266-275), not a sample of them: the oracle's table, which it regenerates from
+    the polynomial, and the remainders x^(111 - b) mod (x^24 + 0xFFF409) computed here."""
+    tab = LIT["modes_checksum_table"]
+    assert len(tab) == 112 and tab[88:] == [0] * 24
+    for idx, val in enumerate(tab):
+        assert O.lib().oracle1090_checksum_entry(idx) == val, idx
+    t = 0xFFF409
+    for j in range(87, -1, -1):
+        assert tab[j] == t, j
+        t <<= 1
+        if t & 0x1000000:
+            t ^= 0x1FFF409
+    # the checksum of a message is the XOR of the entries of its set bits (:277-291): every single-bit message, both lengths
+    for bits, off in ((112, 0), (56, 56)):
+        for j in range(bits):
+            m = bytearray(14)
+            m[j // 8] ^= 0x80 >> (j % 8)
+            assert O.lib().oracle1090_checksum(bytes(m), bits) == tab[j + off]
+
+
+def test_every_literal_of_the_reference_nl_table(native_libs):
+    """The 58 latitude boundaries of CprNlFunction (ADSB1090.cpp:996-1054) as literals: NL drops by one exactly AT each boundary (the
+    comparison is `lat < boundary`), symmetrically about the equator -- in the oracle and in the product's table-driven look-up
+    (resolver1090.cpp; exported as adsb_amd_cpr_nl)."""
+    import libadsb_amd as A
+    bounds = LIT["cpr_nl_boundaries"]
+    assert len(bounds) == 58
+    for fn in (O.lib().oracle1090_cpr_nl, A.lib().adsb_amd_cpr_nl):
+        assert fn(0.0) == 59 and fn(90.0) == 1 and fn(-90.0) == 1
+        for k, b in enumerate(bounds):
+            below, at = np.nextafter(b, 0.0), b
+            for sign in (1.0, -1.0):
+                assert fn(sign * below) == 59 - k, (k, b)
+                assert fn(sign * at) == 58 - k, (k, b)
+
+
+def test_the_reference_character_set_of_identification_frames(native_libs):
+    """AisCharset (ADSB1090.cpp:608) as a literal: all 64 six-bit codes through an identification frame (DF17, type 4), eight per frame --
+    through the oracle's tracker (the call sign it hands the listener) and through the product's host field decoder."""
+    import libadsb_amd as A
+    cs = LIT["ais_charset"]
+    assert len(cs) == 64
+    for base in range(0, 64, 8):
+        codes = list(range(base, base + 8))
+        me = (4 << 51) | sum(c << (42 - 6 * i) for i, c in enumerate(codes))  # type 4, category 0, eight characters
+        msg = bytearray([17 << 3 | 5, 0x48, 0x40, 0xD6]) + me.to_bytes(7, "big") + bytes(3)
+        crc = O.lib().oracle1090_checksum(bytes(msg), 112)
+        msg[11:14] = crc.to_bytes(3, "big")
+        want = cs[base:base + 8]
+        buf = np.full(A.REF_BUFFER_BYTES, 127, dtype=np.uint8)
+        place(buf, modulate(bytes(msg).hex()), 1000)
+        o = O.Oracle1090()
+        frames, aircraft = o.handle_data(buf)
+        assert len(frames) == 1 and aircraft[0]["callsign"] == want.encode("latin-1"), (base, aircraft)
+        rec = np.zeros(1, dtype=A.RECORD_DTYPE)
+        rec["df"], rec["nbits"], rec["errorbit"] = 17, 112, -1
+        rec["msg"][0] = np.frombuffer(bytes(msg), dtype=np.uint8)
+        d = A.decode_records_host(rec)[0]
+        got = int(d["a"]).to_bytes(4, "little") + int(d["b"]).to_bytes(4, "little")
+        assert got == want.encode("latin-1"), (base, got)
+
+
 def test_magnitude_lut_properties():
     lut = np.ctypeslib.as_array(O.lib().oracle1090_mag_lut(), shape=(129 * 129,)).reshape(129, 129)
     assert lut[0, 0] == 0 and lut[1, 0] == 360 and lut[3, 4] == 1800 and lut[128, 128] == 65167
@@ -124,10 +190,15 @@ def test_magnitude_lut_properties():
 
 def test_callback_text_format_matches_reference_goldens():
     pat = re.compile(rb"^([0-9a-f]+)\[(.{8})\]: Pos=([+-]\d+\.\d\d):([+-]\d+\.\d\d)\^(-?\d{5}) Speed=(\d{3,}) Count=(\d+)$", re.S)
-    for name in ("TestEmbedded_modes1.bin.txt", "TestEnv_rtlsdr_10902021-06-25-07-39-00.txt"):
-        lines = open(os.path.join(ROOT, "tests", "golden", "reference", name), "rb").read().split(b"\n")
+    import gzip
+    # (the two 978 files come out of the same listener -- tests/test_1090.cpp:13-42 formats every callback, whichever handler made it --, so
+    # their 42 + 9053 lines pin the same formatter; the larger one is kept compressed)
+    for name in ("TestEmbedded_modes1.bin.txt", "TestEnv_rtlsdr_10902021-06-25-07-39-00.txt", "TestEnv_rtlsdr_978_2021-06-16-20-21-39.txt",
+                 "TestEnv_rtlsdr_978_2021-06-16-22-30-43.txt.gz"):
+        path = os.path.join(ROOT, "tests", "golden", "reference", name)
+        lines = (gzip.open(path, "rb") if name.endswith(".gz") else open(path, "rb")).read().split(b"\n")
         lines = [l for l in lines if l]
-        assert len(lines) in (260, 78)
+        assert len(lines) in (260, 78, 42, 9053)
         for l in lines:
             m = pat.match(l)
             assert m, l
