@@ -472,6 +472,39 @@ typedef __attribute__((address_space(1))) const uint16_t* g_cu16;
 typedef __attribute__((address_space(1))) uint32_t*       g_u32;
 typedef __attribute__((address_space(3))) int16_t*        lds_i16;
 
+// ---- The phase table in LDS, folded (round 5).  The demodulating waves used to gather their tiles' phases from the 128 KB table in
+// global memory: sixteen 64-lane gathers per tile, every lane on a cache line of its own wherever a frame is on the air (its samples go round
+// the IQ plane), each costing the CU's address unit ~64 cycles -- 0.08 of this kernel's 0.21 ms for the ADS-B matches' first tiles alone
+// (profiles/r05_uat978_demod_parts.txt: staging with the look-ups 0.124 ms, without 0.042) and as much again for the uplink frames' ten tiles.
+// The table is atan2 about (127.5, 127.5), so it has the plane's symmetries EXACTLY (checked entry by entry when a handle is made,
+// uat978_host.cpp, and in tests/test_uat978.py): with I' = 255 - I, Q' = 255 - Q
+//     lut(I', Q) = 32768 - lut(I, Q),    lut(I, Q') = -lut(I, Q)      (mod 65536)
+// and the quadrant I, Q >= 128 -- 128 x 128 entries, 32 KB -- is enough: a workgroup of kUatDemodWaves waves shares one copy in LDS.
+constexpr int kUatFoldedEntries = 128 * 128;
+typedef __attribute__((address_space(3))) const uint16_t* lds_cu16;
+
+// phases of the two samples in `w` (packed the same way) from the folded table
+__device__ __forceinline__ uint32_t lut2_folded(lds_cu16 folded, uint32_t w)
+{
+    typedef short          v2s __attribute__((ext_vector_type(2)));
+    typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+    const uint32_t sgn = w & 0x80808080u;                 // per byte: the coordinate is >= 128
+    const uint32_t m   = w ^ (0x7F7F7F7Fu + (sgn >> 7));  // b >= 128: b - 128, else 127 - b (seven bits per byte)
+    // byte offset of entry (mq, mi) = mq << 8 | mi << 1, in both halves at once
+    uint32_t       o2  = (m & 0xFF00FF00u) | ((m << 1) & 0x00FF00FFu);
+    // The bank of an entry is bits 2..7 of its offset = mi's bits 1..6 alone: the samples of a frame (a circle in the IQ plane: |I - 127.5| near
+    // the amplitude for much of the way round) would pile onto a few banks.  Row mq is therefore stored with mq's low six bits XORed into them.
+    o2 ^= (o2 >> 6) & 0x00FC00FCu;
+    const auto     b   = reinterpret_cast<__attribute__((address_space(3))) const char*>(folded);
+    const uint32_t lo  = *reinterpret_cast<lds_cu16>(b + (o2 & 0xFFFFu));
+    const uint32_t hi  = *reinterpret_cast<lds_cu16>(b + (o2 >> 16));
+    uint32_t       ph  = __builtin_amdgcn_perm(hi, lo, 0x05040100u); // hi.word0 : lo.word0
+    const uint32_t isg = sgn << 8;                                   // bit 15 of a half: I >= 128 (bit 15 of sgn: Q >= 128)
+    const uint32_t neg = __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2s, sgn ^ isg) >> (v2s){15, 15}); // exactly one coordinate folded: -phase
+    ph                 = __builtin_bit_cast(uint32_t, (v2u)(__builtin_bit_cast(v2u, ph ^ neg) - __builtin_bit_cast(v2u, neg)));
+    return ph ^ (~isg & 0x80008000u);                                // I folded: + 32768
+}
+
 __device__ __forceinline__ uint32_t draw_ticket(g_u32 counter, int lane)
 { // one statement = issue + wait: the compiler does not track the counter of an asm's load, so the result must be there when the asm ends
     uint32_t t = 0;
@@ -480,7 +513,7 @@ __device__ __forceinline__ uint32_t draw_ticket(g_u32 counter, int lane)
 }
 
 template <bool PHASES_GIVEN>
-__device__ __forceinline__ uint32_t stage_dphi_body(g_cu16 in, g_cu16 lut, uint64_t n, uint64_t base, lds_i16 dphi_s, int lane, g_u32 counter)
+__device__ __forceinline__ uint32_t stage_dphi_body(g_cu16 in, g_cu16 lut, lds_cu16 folded, uint64_t n, uint64_t base, lds_i16 dphi_s, int lane, g_u32 counter)
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); // (HIP's uint4 is a class: no assignment across address spaces)
     typedef __attribute__((address_space(1))) const u32x4* g_cu4;
@@ -492,6 +525,7 @@ __device__ __forceinline__ uint32_t stage_dphi_body(g_cu16 in, g_cu16 lut, uint6
     auto uniform64 = [](uint64_t v) { return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v); };
     in = (g_cu16)uniform64((uint64_t)in), lut = (g_cu16)uniform64((uint64_t)lut), counter = (g_u32)uniform64((uint64_t)counter);
     base = uniform64(base), n = uniform64(n);
+    folded = (lds_cu16)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)folded);
     const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
     if (aligned && base + (uint64_t)kUatTile + 1 <= n)
     { // the whole tile and the sample after it lie inside the stream (wave-uniform; every tile but a stream's last few): no guards,
@@ -508,17 +542,10 @@ __device__ __forceinline__ uint32_t stage_dphi_body(g_cu16 in, g_cu16 lut, uint6
 #pragma unroll
             for (int k = 0; k < 4; k++)
             {
-                if (PHASES_GIVEN) p[r][k] = w[k];
-                else
-                {
-                    const auto     b  = reinterpret_cast<__attribute__((address_space(1))) const char*>(lut);
-                    const uint32_t lo = *reinterpret_cast<g_cu16>(b + table_offset_lo(w[k]));
-                    const uint32_t hi = *reinterpret_cast<g_cu16>(b + table_offset_hi(w[k]));
-                    p[r][k]           = __builtin_amdgcn_perm(hi, lo, 0x05040100u); // hi.word0 : lo.word0
-                }
+                p[r][k] = PHASES_GIVEN ? w[k] : lut2_folded(folded, w[k]);
             }
         }
-        const uint32_t after_ph = PHASES_GIVEN ? after : (uint32_t)lut[after];
+        const uint32_t after_ph = PHASES_GIVEN ? after : lut2_folded(folded, after) & 0xFFFFu;
         if (counter) ticket = draw_ticket(counter, lane);
 #pragma unroll
         for (int r = 0; r < 2; r++)
@@ -564,9 +591,9 @@ __device__ __forceinline__ uint32_t stage_dphi_body(g_cu16 in, g_cu16 lut, uint6
 }
 
 template <bool PHASES_GIVEN>
-__device__ __noinline__ uint32_t stage_dphi(g_cu16 in, g_cu16 lut, uint64_t n, uint64_t base, lds_i16 dphi_s, int lane, g_u32 counter)
+__device__ __noinline__ uint32_t stage_dphi(g_cu16 in, g_cu16 lut, lds_cu16 folded, uint64_t n, uint64_t base, lds_i16 dphi_s, int lane, g_u32 counter)
 {
-    return stage_dphi_body<PHASES_GIVEN>(in, lut, n, base, dphi_s, lane, counter);
+    return stage_dphi_body<PHASES_GIVEN>(in, lut, folded, n, base, dphi_s, lane, counter);
 }
 
 // the sync re-check, the sign windows and the slicing on the staged tile; `off` = the first sample's index inside the tile
@@ -1059,9 +1086,11 @@ __device__ unsigned long long g_uat_diag[2][8]; // [kind][phase]; phase 7 = posi
 #endif
 enum { kDiagStage = 0, kDiagSync, kDiagSlice, kDiagSyndromes, kDiagDecode, kDiagMoreTiles, kDiagOutput };
 
-constexpr int kUatDemodWaves = 7; // per SIMD (67 vector registers; at eight the kernel spills and gains nothing, profiles/r04_uat978_demod_sweep.txt)
+// Waves of a demodulating workgroup: they share the folded phase table (32 KB) and the Reed-Solomon tables and have ~4 KB each of their own.
+// Two workgroups per CU: 2 x (32 KB + 0.75 KB + 8 x 4 KB) = 131 KB, which leaves room for a decision kernel's workgroup (20 KB) of another call.
+constexpr int kUatDemodWaves = 12;
 template <bool PHASES_GIVEN>
-__global__ __launch_bounds__(64, kUatDemodWaves) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
+__global__ __launch_bounds__(64 * kUatDemodWaves, 6) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
                                                        const RsTables* __restrict__ rs_tables, const uint32_t* __restrict__ cand, uint32_t ncand,
                                                        uat_rec_t* __restrict__ recs, uint8_t* __restrict__ payloads, uint8_t* __restrict__ uplink_payloads,
                                                        uint32_t uplink_cap,
@@ -1070,19 +1099,34 @@ __global__ __launch_bounds__(64, kUatDemodWaves) void uat_demod_kernel(const uin
                                                        int64_t lenbits, uint32_t* __restrict__ next_bit, uat_extra_t* __restrict__ extras,
                                                        uint8_t* __restrict__ extra_payloads, uint32_t extra_cap, uint32_t* __restrict__ counts)
 {
+    struct WaveArea // a wave's own
+    {
+        __attribute__((aligned(16))) int16_t dphi_s[kUatTile];
+        uint8_t raw[2][kUatUplinkBytes + 8];
+        RsWork  work[6];
+    };
     __shared__ RsTables T;
-    __shared__ uint8_t  raw[2][kUatUplinkBytes + 8];
-    __shared__ uint8_t  sliced[kUatLongBytes];
-    __shared__ RsWork   work[6];
-    __shared__ __attribute__((aligned(16))) int16_t dphi_s[kUatTile];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < (int)sizeof(RsTables) / 4; i += 64) reinterpret_cast<uint32_t*>(&T)[i] = reinterpret_cast<const uint32_t*>(rs_tables)[i];
-    wave_fence();
+    __shared__ __attribute__((aligned(16))) uint16_t folded[PHASES_GIVEN ? 2 : kUatFoldedEntries];
+    __shared__ WaveArea areas[kUatDemodWaves];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (said to be uniform: the wave's LDS addresses stay on the scalar side)
+    for (int i = threadIdx.x; i < (int)sizeof(RsTables) / 4; i += 64 * kUatDemodWaves) reinterpret_cast<uint32_t*>(&T)[i] = reinterpret_cast<const uint32_t*>(rs_tables)[i];
+    if constexpr (!PHASES_GIVEN)
+        for (int i = threadIdx.x; i < kUatFoldedEntries / 2; i += 64 * kUatDemodWaves)
+        { // entries (mq, mi) and (mq, mi + 1) = lut[128 + mq][128 + mi ..]: one dword of the table's row 128 + mq
+            const int mq = i >> 6, mi = 2 * (i & 63);
+            reinterpret_cast<uint32_t*>(folded)[i ^ (mq & 63)] = *reinterpret_cast<const uint32_t*>(lut + (((128 + mq) << 8) | (128 + mi))); // (lut2_folded's bank swizzle)
+        }
+    __syncthreads(); // the only one: from here on the waves go their own ways
+    auto& raw    = areas[wave].raw;
+    auto& work   = areas[wave].work;
+    auto& dphi_s = areas[wave].dphi_s;
 
     // Candidates differ a lot in cost (noise that fails the sync re-check, short frames whose long-code attempt has to fail
     // first, uplink frames with twelve code words), so they are handed out by work counters, not by a fixed stride: the list
     // is cut into `nranges` pieces, each with a counter on its own cache line; a block takes its first candidate by position.
-    const uint32_t range = blockIdx.x % nranges, slot = blockIdx.x / nranges, nslot = gridDim.x / nranges;
+    // (wave w of the grid's gridDim.x * kUatDemodWaves: range w mod nranges, slot w / nranges; the waves beyond nranges * nslot have nothing to do)
+    const uint32_t gwave = blockIdx.x * kUatDemodWaves + (uint32_t)wave, nslot = gridDim.x * kUatDemodWaves / nranges;
+    const uint32_t range = gwave % nranges, slot = gwave / nranges;
     const uint32_t per   = (ncand + nranges - 1) / nranges;
     const uint32_t first = range * per < ncand ? range * per : ncand, end = first + per < ncand ? first + per : ncand;
     // Uplink matches first (up_list, dealt round-robin to the ranges), then the range's own slice of the list with the uplink
@@ -1094,7 +1138,7 @@ __global__ __launch_bounds__(64, kUatDemodWaves) void uat_demod_kernel(const uin
     const LongExponents  long_exp  = syndrome_exponents<48, 4>(lane);
     const ShortExponents short_exp = syndrome_exponents<30, 3>(lane);
     UAT_DIAG_DECLARE();
-    for (uint32_t item = slot; item < nitems;)
+    for (uint32_t item = slot < nslot ? slot : nitems; item < nitems;)
     {
         const bool     from_list = item < nup_r;
         const uint32_t c         = from_list ? up_list[range + item * nranges] : first + (item - nup_r);
@@ -1112,15 +1156,19 @@ __global__ __launch_bounds__(64, kUatDemodWaves) void uat_demod_kernel(const uin
         // lane-varying, and a value carried through it would live in a vector register.)
         wave_fence(); // the previous match's readers are done with the tile
         const uint32_t next_item = nslot + (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_dphi<PHASES_GIVEN>(
-                                               (g_cu16)in, (g_cu16)lut, n, (uint64_t)(word & 0x7FFFFFF8u), (lds_i16)dphi_s, lane, my_counter));
+                                               (g_cu16)in, (g_cu16)lut, (lds_cu16)folded, n, (uint64_t)(word & 0x7FFFFFF8u), (lds_i16)dphi_s, lane, my_counter));
         // After the match's own frame: the frames the scan loop would take behind it through stale register bits (see StaleWindow).
         // They are demodulated by this wave, by the same code: the body below runs once per position.  All of this is wave-uniform.
         StaleWindow stale;
         bool        chained = false; // the position being demodulated is such an extra, not the match
         uint32_t    seq     = 0;
+        uint32_t    sink    = 0; // measurement builds (diag::kUatParts): what keeps the parts left in from being optimised away
         for (;;)
         {
         const uint32_t kind = word >> 31;
+        bool cut = false; // (a match that is cut short leaves as one at which nothing decodes)
+        if constexpr (diag::kUatParts <= 6) cut = kind != 0;
+        if constexpr (diag::kUatParts == 1) cut = true;
         const uint64_t idx  = word & 0x7FFFFFFFu;
         const uint64_t sb   = idx >> 1;
         const uint64_t base = (2 * sb) & ~7ull;           // tile 0 starts here (16-byte aligned in the stream)
@@ -1130,7 +1178,7 @@ __global__ __launch_bounds__(64, kUatDemodWaves) void uat_demod_kernel(const uin
         if (chained)
         {
             wave_fence(); // the previous position's readers are done with the tile
-            stage_dphi<PHASES_GIVEN>((g_cu16)in, (g_cu16)lut, n, base, (lds_i16)dphi_s, lane, (g_u32) nullptr);
+            stage_dphi<PHASES_GIVEN>((g_cu16)in, (g_cu16)lut, (lds_cu16)folded, n, base, (lds_i16)dphi_s, lane, (g_u32) nullptr);
         }
         wave_fence();
         UAT_DIAG_LAP(kDiagStage);
@@ -1140,21 +1188,34 @@ __global__ __launch_bounds__(64, kUatDemodWaves) void uat_demod_kernel(const uin
         // frames from sample idx (variant 0) and idx + 1 (variant 1); all of this is wave-uniform.  The variant with fewer corrected
         // symbols is taken and the first on a tie, so a variant 0 that decodes without corrections makes variant 1 irrelevant.
         int skip0 = 0, skip1 = 0, rs0 = 9999, rs1 = 9999;
-        if (kind == 0)
+        if (cut) sink += (uint32_t)dphi_s[word & 63u];
+        else if (kind == 0)
         { // everything an ADS-B match needs lies in tile 0 (the last window ends 914 samples after its start)
             w1 = sign_window_tile(dphi_s, oe + 2 * (kUatShortSkip + 1), lane);
             w2 = sign_window_tile(dphi_s, oe + 2 * (kUatLongSkip + 1), lane);
             bool sliced0 = false; // sliced0: sliced[] holds variant 0's 48 bytes as sliced, before any correction
+            static_assert(sizeof(RsWork) >= kUatLongBytes, "room for the copy");
+            uint8_t* const sliced = reinterpret_cast<uint8_t*>(&work[2]); // (an ADS-B match works in work[0] and work[1] only)
 #pragma unroll 1
             for (int v = 0; v < 2; v++)
             {
                 if (v == 1 && skip0 && rs0 == 0) break;
                 const SyncCheck sc = check_sync_tile(dphi_s, o + v, false, lane);
                 UAT_DIAG_LAP(kDiagSync);
+                if constexpr (diag::kUatParts == 2)
+                {
+                    sink += (uint32_t)sc.ok + (uint32_t)sc.center;
+                    continue;
+                }
                 if (!sc.ok) continue;
                 slice_bytes_tile(dphi_s, o + v + 72, sc.center, 0, nbits / 8, raw[v], lane);
                 wave_fence();
                 UAT_DIAG_LAP(kDiagSlice);
+                if constexpr (diag::kUatParts == 3)
+                {
+                    sink += raw[v][word & 31u];
+                    continue;
+                }
                 if (v == 1 && sliced0 && __ballot(lane < kUatLongBytes && raw[1][lane] != sliced[lane]) == 0)
                 { // Both alignments slice to the same 48 bytes (two samples per bit: the rule for a signal well above the noise), so
                   // they decode alike and the tie goes to variant 0: nothing left to do for variant 1.
@@ -1164,6 +1225,17 @@ __global__ __launch_bounds__(64, kUatDemodWaves) void uat_demod_kernel(const uin
                 syndromes_fixed_wave<48, 14>(T, raw[v], work[v].s, lane, long_exp);
                 wave_fence();
                 UAT_DIAG_LAP(kDiagSyndromes);
+                if constexpr (diag::kUatParts == 4)
+                {
+                    sink += work[v].s[word & 7u];
+                    if (v == 0)
+                    { // (as below, so that the second alignment is passed over as often as in the product)
+                        if (lane < kUatLongBytes) sliced[lane] = raw[0][lane];
+                        lane0_join();
+                        sliced0 = true;
+                    }
+                    continue;
+                }
                 if (v == 0)
                 { // the decoders correct in place
                     if (lane < kUatLongBytes) sliced[lane] = raw[0][lane];
@@ -1174,6 +1246,12 @@ __global__ __launch_bounds__(64, kUatDemodWaves) void uat_demod_kernel(const uin
                 const int skip_v = __builtin_amdgcn_readfirstlane(correct_adsb_wave(T, raw[v], work[v], lane, &rs_v, &short_exp));
                 rs_v             = __builtin_amdgcn_readfirstlane(rs_v);
                 UAT_DIAG_LAP(kDiagDecode);
+                if constexpr (diag::kUatParts == 5)
+                {
+                    sink += (uint32_t)skip_v + (uint32_t)rs_v;
+                    if (v == 0 && skip_v && rs_v == 0) break; // (the product's exit at the head of the loop)
+                    continue;
+                }
                 if (v == 0) skip0 = skip_v, rs0 = rs_v;
                 else skip1 = skip_v, rs1 = rs_v;
             }
@@ -1198,7 +1276,7 @@ __global__ __launch_bounds__(64, kUatDemodWaves) void uat_demod_kernel(const uin
                     if (t > 0)
                     {
                         wave_fence();
-                        stage_dphi<PHASES_GIVEN>((g_cu16)in, (g_cu16)lut, n, base + (uint64_t)(t * kUatTileStride), (lds_i16)dphi_s, lane, (g_u32) nullptr);
+                        stage_dphi<PHASES_GIVEN>((g_cu16)in, (g_cu16)lut, (lds_cu16)folded, n, base + (uint64_t)(t * kUatTileStride), (lds_i16)dphi_s, lane, (g_u32) nullptr);
                         wave_fence();
                         UAT_DIAG_LAP(kDiagMoreTiles);
                     }
@@ -1281,7 +1359,7 @@ __global__ __launch_bounds__(64, kUatDemodWaves) void uat_demod_kernel(const uin
         {
             r->index = (uint32_t)idx, r->kind = (uint8_t)kind, r->variant = (uint8_t)v_take;
             r->skip = (int16_t)skip_t, r->rs = (uint8_t)(v_take < 2 ? rs_t : 255);
-            r->slot = up_slot, r->window = w0;
+            r->slot = up_slot, r->window = diag::kUatParts <= 6 ? w0 + sink : w0;
             r->after = after;
         }
         wave_fence(); // raw[] is reused by the next position
@@ -1699,8 +1777,12 @@ hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, bool ordered, h
 {
     if (ncand == 0) return hipSuccess;
     const uint32_t nranges = ncand >= 4096 ? kUatDemodRanges : 1u;
-    uint32_t       g       = ncand > 8192 ? 8192 : ncand; // (exactly as many workgroups as the device holds at once -- 7168 -- measured: no better)
-    g                      = ((g + nranges - 1) / nranges) * nranges;
+    // one wave per match up to what the device holds at once (two workgroups per CU, 256 CUs: the waves draw tickets from there on)
+    constexpr uint32_t kResidentWaves = 2 * 256 * kUatDemodWaves;
+    
+    uint32_t waves = ncand > kResidentWaves ? kResidentWaves : ncand;
+    waves          = ((waves + nranges - 1) / nranges) * nranges;
+    const uint32_t g = (waves + kUatDemodWaves - 1) / kUatDemodWaves;
     if (!ordered && ncand > 1)
     { // (a single look-up needs no reset: one wave, one item, and the loop ends whatever the counter holds; the next ordering pass zeroes it)
         hipError_t e = hipMemsetAsync(a.demod_work, 0, kUatDemodRanges * 32 * sizeof(uint32_t), stream);
@@ -1710,11 +1792,11 @@ hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, bool ordered, h
     const uint32_t* up_count = ordered ? a.counts + 2 : nullptr;
     uint32_t*       chase    = ordered ? a.next_bit : nullptr; // the frames behind a frame are followed for the ordered list only
     if (a.phases_given)
-        hipLaunchKernelGGL(uat_demod_kernel<true>, dim3(g), dim3(64), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
+        hipLaunchKernelGGL(uat_demod_kernel<true>, dim3(g), dim3(64 * kUatDemodWaves), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
                            a.payloads, a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges, up_list, up_count, a.single_word,
                            a.lenbits, chase, a.extras, a.extra_payloads, a.extra_cap, a.counts);
     else
-        hipLaunchKernelGGL(uat_demod_kernel<false>, dim3(g), dim3(64), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
+        hipLaunchKernelGGL(uat_demod_kernel<false>, dim3(g), dim3(64 * kUatDemodWaves), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
                            a.payloads, a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges, up_list, up_count, a.single_word,
                            a.lenbits, chase, a.extras, a.extra_payloads, a.extra_cap, a.counts);
     return hipGetLastError();

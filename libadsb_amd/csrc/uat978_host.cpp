@@ -238,6 +238,19 @@ struct adsb_amd_uat
                 const double scaled = std::round(32768 * ang / M_PI);
                 lut_h[i | (q << 8)] = (uint16_t)(scaled < 0 ? 0 : scaled > 65535 ? 65535 : scaled);
             }
+        // The demodulation kernel keeps one quadrant of the table in LDS and derives the others (uat978.hip, lut2_folded): that is only
+        // the same table if the symmetries hold entry by entry.  They do for this formula (no entry comes within 1e-4 of a rounding tie);
+        // a library or compiler whose atan2 breaks them must not demodulate with a different table in silence.
+        for (unsigned i = 0; i < 256; i++)
+            for (unsigned q = 0; q < 256; q++)
+            {
+                const uint16_t v = lut_h[i | (q << 8)];
+                if ((uint16_t)(v + lut_h[i | ((255 - q) << 8)]) != 0 || (uint16_t)(v + lut_h[(255 - i) | (q << 8)]) != 32768)
+                {
+                    error = "the phase table lacks the symmetries the demodulation kernel folds it by";
+                    return ADSB_AMD_ESTATE;
+                }
+            }
         UAT_HIP(hipMalloc(&lut_d, 65536 * sizeof(uint16_t)));
         UAT_HIP(hipMemcpy(lut_d, lut_h.data(), 65536 * sizeof(uint16_t), hipMemcpyHostToDevice));
         UAT_HIP(hipMalloc(&rs_d, sizeof(RsTables)));
