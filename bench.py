@@ -215,7 +215,7 @@ def main():
             try:
                 u = bench_uat978(argparse.Namespace(**{**vars(args), "steps": max(50, min(args.steps, 100)), "warmup": min(args.warmup, 3)}),  # (its own step count, reported in the block: a window of calls in flight starts and ends with an empty pipeline, 0.75 ms for its first call)
                                  0, local_rank, 1, None, A, synth, torch)
-                out["uat978"] = {k: u[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "frames_per_step",
+                out["uat978"] = {k: u[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "path_roofline", "frames_per_step",
                                                    "demod_kernel_ms", "dominant_kernel", "matches_per_step_rank0", "pipelined", "ms_per_step_serial", "timing",
                                                    "host_wall_ms_last_step", "cpu_baseline") if k in u}
             except Exception as e:  # the headline line must not be lost to the second workload

@@ -28,6 +28,25 @@ def test_phase_lut_known_answers():
     assert np.all(np.abs(((a - b) % 65536) - 32768) <= 1)
 
 
+def test_phase_lut_has_exactly_the_symmetries_the_demodulation_kernel_folds_it_by():
+    """uat978.hip keeps the quadrant I, Q >= 128 in LDS (lut2_folded) and derives the rest: lut(255 - I, Q) = 32768 - lut(I, Q) and
+    lut(I, 255 - Q) = -lut(I, Q), mod 65536, for every one of the 65 536 entries (the handle checks the same of its own table when it
+    is made); no entry is near a rounding tie."""
+    lut = O.phase_lut978().astype(np.int64)
+    i, q = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    v = lut[i | (q << 8)]
+    assert np.all((v + lut[i | ((255 - q) << 8)]) % 65536 == 0)
+    assert np.all((v + lut[(255 - i) | (q << 8)]) % 65536 == 32768)
+    x = 32768 * (np.arctan2(q - 127.5, i - 127.5) + np.pi) / np.pi
+    assert np.min(np.abs(x - np.floor(x) - 0.5)) > 1e-4
+    # the folded look-up itself, as the kernel does it: magnitudes, the quadrant's entry, the two corrections
+    mi, mq = np.where(i >= 128, i - 128, 127 - i), np.where(q >= 128, q - 128, 127 - q)
+    f = lut[(128 + mi) | ((128 + mq) << 8)]
+    f = np.where((i >= 128) != (q >= 128), -f, f)
+    f = np.where(i < 128, f + 32768, f) % 65536
+    assert np.array_equal(f, v)
+
+
 @pytest.mark.parametrize("kind", [0, 1, 2])
 def test_rs_encode_decode_round_trip(kind):
     rng = np.random.default_rng(978 + kind)

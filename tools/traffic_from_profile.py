@@ -42,21 +42,26 @@ def first_with_counters(kernel, *names):
 
 
 res = {}
-p = first_with_counters("scan1090", "r04_final_rocprof_summary.txt", "r03_final_rocprof_summary.txt", "r02_final_rocprof_summary.txt", "r01_final_rocprof_summary.txt")
+def rounds(pattern):
+    """the summaries of every round for one workload, newest first"""
+    return [pattern % n for n in range(9, 0, -1)]
+
+
+p = first_with_counters("scan1090", *rounds("r0%d_final_rocprof_summary.txt"))
 if p:
     m = means(p, "scan1090")
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         res["1073741824"] = {"traffic_bytes": int(round((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024)), "FETCH_SIZE_KB": m["FETCH_SIZE"], "WRITE_SIZE_KB": m["WRITE_SIZE"],
                              "kernel": "scan1090_kernel", "source": os.path.relpath(p, ROOT),
                              "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on the 1 GiB bench workload; FETCH_SIZE doubled (gfx950 counts half of wide coalesced reads)"}
-p = first_with_counters("uat_scan_iq", "r04_uat978_rocprof_summary.txt", "r03_uat978_rocprof_summary.txt", "r02_uat978_rocprof_summary.txt", "r01_uat978_rocprof_summary.txt")
+p = first_with_counters("uat_scan_iq", *rounds("r0%d_uat978_rocprof_summary.txt"))
 if p:
     m = means(p, "uat_scan_iq")
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         res["uat978:1073741824"] = {"traffic_bytes": int(round((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024)), "FETCH_SIZE_KB": m["FETCH_SIZE"],
                                     "WRITE_SIZE_KB": m["WRITE_SIZE"], "kernel": "uat_scan_iq_kernel", "source": os.path.relpath(p, ROOT),
                                     "note": "as above, tools/uat_pmc.sh"}
-p = first_with_counters("scan2400", "r04_mode2400_rocprof_summary.txt", "r03_mode2400_rocprof_summary.txt")
+p = first_with_counters("scan2400", *rounds("r0%d_mode2400_rocprof_summary.txt"))
 if p:
     m = means(p, "scan2400")
     res["mode2400:1073741824"] = {"traffic_bytes": int(round((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024)), "FETCH_SIZE_KB": m["FETCH_SIZE"],
