@@ -63,7 +63,7 @@ def parse_args(argv=None):
                     "the kernel is checked against its specification oracle/oracle2400.c")
     ap.add_argument("--time-every", type=int, default=4, help="HIP events around the scan kernel on every n-th launch of the timed region (1: all)")
     ap.add_argument("--noise", type=int, default=None, help="N = 1: background noise amplitude of the synthetic input (default 3, the BASELINE workload; "
-                    "any other value is a sensitivity run, labelled as such: profiles/r04_sensitivity.txt)")
+                    "any other value is a sensitivity run, labelled as such: profiles/r05_sensitivity.txt)")
     ap.add_argument("--spacing", type=int, default=None, help="N = 1: mean frame start-to-start spacing in samples (default 2000)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the end_to_end and uat978 blocks (profiling runs)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N > 1 ranks all on cuda:0 with the gloo backend: exercises the "
@@ -919,19 +919,20 @@ def bench_uat978(args, rank, local_rank, world, dist, A, synth, torch):
                               "achieved_serial": round(alg_bytes / (elapsed_serial / args.steps) / 1e9, 1),
                               "frac_serial": round(alg_bytes / (elapsed_serial / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                               "note": "whole path per GPU: scan + ordering + demodulation + decisions + the host's walk; the demodulation kernel is "
-                                      "bound by vector-instruction issue, not by memory (dominant_kernel)"},
+                                      "bound by the number of its waves in flight (dependent chains of table look-ups and scalar decisions), not by "
+                                      "memory: profiles/r05_uat978_demod_parts.txt"},
             "frames_per_step": nframes_all, "demod_kernel_ms": round(demod_k, 4), "matches_per_step_rank0": int(matches),
             "pipelined": not args.serial, "ms_per_step_serial": round(elapsed_serial / args.steps * 1e3, 4),
             "timing": "serial: one window of `steps` calls; pipelined (ms_per_step, value): median of three such windows",
             "host_wall_ms_last_step": tm["host_wall_ms"],
         }
         if demod_k > scan_k:
-            # per-match kernel, instruction-bound (PMC, profiles/r04_uat978_rocprof_summary.txt): its algorithmic bytes are the phases of
+            # per-match kernel, instruction-bound (PMC, profiles/r05_uat978_rocprof_summary.txt): its algorithmic bytes are the phases of
             # the matches' frames, far below any HBM bound
             out["dominant_kernel"] = {"kernel": "uat_demod_kernel", "kernel_ms": round(demod_k, 4), "matches": int(matches),
                                       "us_per_1000_matches": round(demod_k * 1e3 / max(1, matches) * 1e3, 2),
                                       "note": "dominant by time; instruction-bound (sync re-check, slicing, Reed-Solomon per match; counters in "
-                                              "profiles/r04_uat978_rocprof_summary.txt), not bandwidth-bound: the HBM roofline "
+                                              "profiles/r05_uat978_rocprof_summary.txt), not bandwidth-bound: the HBM roofline "
                                               "above is the scan kernel's, the only kernel of this path that streams the input"}
         if world == 1 and args.cpu_buffers > 0:
             from oracle import oracle_py as O
