@@ -512,12 +512,48 @@ __device__ __forceinline__ uint32_t draw_ticket(g_u32 counter, int lane)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); // (HIP's uint4 is a class: no assignment across address spaces)
+typedef __attribute__((address_space(1))) const u32x4* g_cu4;
+typedef __attribute__((address_space(3))) u32x4*       lds_u4;
+
+// A tile whose 1024 samples and the sample after them lie inside the stream, as loaded (lane l: samples 8 l .. 8 l + 7 in x0, 8 (l + 64) .. in x1),
+// to phase differences in LDS: two phases per register, the pair shifted by one sample from v_alignbit, two wrapped differences per v_pk_sub_i16.
+template <bool PHASES_GIVEN>
+__device__ __forceinline__ void tile_to_lds(u32x4 x0, u32x4 x1, uint32_t after, lds_cu16 folded, lds_i16 dphi_s, int lane)
+{
+    const u32x4 x[2] = {x0, x1};
+    uint32_t    p[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+    {
+        const uint32_t w[4] = {x[r].x, x[r].y, x[r].z, x[r].w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) p[r][k] = PHASES_GIVEN ? w[k] : lut2_folded(folded, w[k]);
+    }
+    const uint32_t after_ph = PHASES_GIVEN ? after : lut2_folded(folded, after) & 0xFFFFu; // (only lane 63 of round 1 uses it)
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+    {
+        const uint32_t wrap = r == 0 ? (uint32_t)__builtin_amdgcn_readlane((int)p[1][0], 0) : after_ph;
+        const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp((int)wrap, (int)p[r][0], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+        const uint32_t p12 = __builtin_amdgcn_alignbit(p[r][1], p[r][0], 16), p34 = __builtin_amdgcn_alignbit(p[r][2], p[r][1], 16);
+        const uint32_t p56 = __builtin_amdgcn_alignbit(p[r][3], p[r][2], 16), p78 = __builtin_amdgcn_alignbit(next, p[r][3], 16);
+        *reinterpret_cast<lds_u4>(dphi_s + 8 * (lane + 64 * r)) =
+            u32x4{pk_sub_i16(p12, p[r][0]), pk_sub_i16(p34, p[r][1]), pk_sub_i16(p56, p[r][2]), pk_sub_i16(p78, p[r][3])};
+    }
+}
+// (out of line for the registers, like stage_dphi: the caller loaded the tile itself, while it was still busy with the tile before)
+template <bool PHASES_GIVEN>
+__device__ __noinline__ void stage_loaded_tile(u32x4 x0, u32x4 x1, uint32_t after, lds_cu16 folded, lds_i16 dphi_s, int lane)
+{
+    folded = (lds_cu16)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)folded);
+    dphi_s = (lds_i16)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)dphi_s);
+    tile_to_lds<PHASES_GIVEN>(x0, x1, after, folded, dphi_s, lane);
+}
+
 template <bool PHASES_GIVEN>
 __device__ __forceinline__ uint32_t stage_dphi_body(g_cu16 in, g_cu16 lut, lds_cu16 folded, uint64_t n, uint64_t base, lds_i16 dphi_s, int lane, g_u32 counter)
 {
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); // (HIP's uint4 is a class: no assignment across address spaces)
-    typedef __attribute__((address_space(1))) const u32x4* g_cu4;
-    typedef __attribute__((address_space(3))) u32x4*       lds_u4;
     uint32_t   ticket  = 0xFFFFFFFFu;
     // the arguments of a function arrive in vector registers; the stream, the table and the counter are the same for every lane: as scalar
     // bases the sixteen look-ups need a 32-bit offset register each instead of a 64-bit address (what the caller may keep live across
@@ -528,35 +564,11 @@ __device__ __forceinline__ uint32_t stage_dphi_body(g_cu16 in, g_cu16 lut, lds_c
     folded = (lds_cu16)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)folded);
     const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
     if (aligned && base + (uint64_t)kUatTile + 1 <= n)
-    { // the whole tile and the sample after it lie inside the stream (wave-uniform; every tile but a stream's last few): no guards,
-      // two phases per register, the pair shifted by one sample from v_alignbit, two wrapped differences per v_pk_sub_i16
-        u32x4    x[2];
-        uint32_t after; // the sample behind the tile: only lane 63 of round 1 uses it
-        x[0] = *reinterpret_cast<g_cu4>(in + base + 8ull * (uint64_t)lane), x[1] = *reinterpret_cast<g_cu4>(in + base + 8ull * (uint64_t)(lane + 64));
-        after = in[base + (uint64_t)kUatTile];
-        uint32_t p[2][4];
-#pragma unroll
-        for (int r = 0; r < 2; r++)
-        {
-            const uint32_t w[4] = {x[r].x, x[r].y, x[r].z, x[r].w};
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-            {
-                p[r][k] = PHASES_GIVEN ? w[k] : lut2_folded(folded, w[k]);
-            }
-        }
-        const uint32_t after_ph = PHASES_GIVEN ? after : lut2_folded(folded, after) & 0xFFFFu;
+    { // the whole tile and the sample after it lie inside the stream (wave-uniform; every tile but a stream's last few): no guards
+        const u32x4    x0 = *reinterpret_cast<g_cu4>(in + base + 8ull * (uint64_t)lane), x1 = *reinterpret_cast<g_cu4>(in + base + 8ull * (uint64_t)(lane + 64));
+        const uint32_t after = in[base + (uint64_t)kUatTile];
         if (counter) ticket = draw_ticket(counter, lane);
-#pragma unroll
-        for (int r = 0; r < 2; r++)
-        {
-            const uint32_t wrap = r == 0 ? (uint32_t)__builtin_amdgcn_readlane((int)p[1][0], 0) : after_ph;
-            const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp((int)wrap, (int)p[r][0], 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-            const uint32_t p12 = __builtin_amdgcn_alignbit(p[r][1], p[r][0], 16), p34 = __builtin_amdgcn_alignbit(p[r][2], p[r][1], 16);
-            const uint32_t p56 = __builtin_amdgcn_alignbit(p[r][3], p[r][2], 16), p78 = __builtin_amdgcn_alignbit(next, p[r][3], 16);
-            *reinterpret_cast<lds_u4>(dphi_s + 8 * (lane + 64 * r)) =
-                u32x4{pk_sub_i16(p12, p[r][0]), pk_sub_i16(p34, p[r][1]), pk_sub_i16(p56, p[r][2]), pk_sub_i16(p78, p[r][3])};
-        }
+        tile_to_lds<PHASES_GIVEN>(x0, x1, after, folded, dphi_s, lane);
         return ticket;
     }
     if (counter) ticket = draw_ticket(counter, lane);
@@ -1271,14 +1283,30 @@ __global__ __launch_bounds__(64 * kUatDemodWaves, 6) void uat_demod_kernel(const
             { // an uplink frame spans ten tiles; group g of variant v starts at sample o + v + 72 + 128 g after the first tile's start
                 constexpr int kTiles = 10;
                 static_assert(72 + 9 + 128 * (kUatUplinkBits / 64 - 1) + 127 < kTiles * kUatTileStride + (kUatTileValid - kUatTileStride), "tiles cover the frame");
+                // A tile's samples set out while the tile before it is sliced (nine trips to memory that used to stand between the slicings, one
+                // after the other).  The loads are issued without a branch around them -- a value defined on one side of a branch is merged where
+                // the sides meet, and the merge waits for it -- so a tile that does not lie wholly inside the stream is loaded from addresses that
+                // do (clamped; the stream holds this match: at least 36 samples), its registers are ignored and stage_dphi's guarded path takes it.
+                const bool     aligned_in = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
+                const g_cu16   in_16      = (g_cu16)(reinterpret_cast<uintptr_t>(in) & ~(uintptr_t)15u);
+                const uint64_t last_oct   = (n & ~7ull) - 8;
+                u32x4          nx0 = {0, 0, 0, 0}, nx1 = {0, 0, 0, 0};
+                uint32_t       nafter = 0;
                 for (int t = 0; t < kTiles; t++)
                 {
+                    const uint64_t tbase = base + (uint64_t)(t * kUatTileStride);
                     if (t > 0)
                     {
                         wave_fence();
-                        stage_dphi<PHASES_GIVEN>((g_cu16)in, (g_cu16)lut, (lds_cu16)folded, n, base + (uint64_t)(t * kUatTileStride), (lds_i16)dphi_s, lane, (g_u32) nullptr);
+                        if (aligned_in && tbase + (uint64_t)kUatTile + 1 <= n) stage_loaded_tile<PHASES_GIVEN>(nx0, nx1, nafter, (lds_cu16)folded, (lds_i16)dphi_s, lane);
+                        else stage_dphi<PHASES_GIVEN>((g_cu16)in, (g_cu16)lut, (lds_cu16)folded, n, tbase, (lds_i16)dphi_s, lane, (g_u32) nullptr);
                         wave_fence();
                         UAT_DIAG_LAP(kDiagMoreTiles);
+                    }
+                    { // (behind the last tile too: a branch here would be the merge the comment above speaks of)
+                        const uint64_t nb = tbase + (uint64_t)kUatTileStride, a0 = nb + 8ull * (uint64_t)lane, a1 = nb + 8ull * (uint64_t)(lane + 64), aa = nb + (uint64_t)kUatTile;
+                        nx0 = *reinterpret_cast<g_cu4>(in_16 + (a0 < last_oct ? a0 : last_oct)), nx1 = *reinterpret_cast<g_cu4>(in_16 + (a1 < last_oct ? a1 : last_oct));
+                        nafter = in_16[aa < n ? aa : n - 1];
                     }
 #pragma unroll
                     for (int v = 0; v < 2; v++)
