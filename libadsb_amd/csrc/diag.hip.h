@@ -2,7 +2,7 @@
 //
 // The library the tests, bench.py and the adapters load is built WITHOUT ADSB_AMD_DIAG_BUILD: every constant below then has its product
 // value, every `if (diag::k...)` in the kernels folds away and stamp() is empty.  tools/build_variant.sh makes measurement builds
-// (ab_libs/<name>.so, never shipped, never loaded by the suite):
+// (/tmp/ab_libs/<name>.so: outside the repository, never loaded by the suite; what an A/B needs on the GPU box is copied to ab_ship/ for that call):
 //     -DADSB_AMD_DIAG_BUILD=1 -DDIAG_PARTS=n        scan1090_kernel / scan2400_kernel with the later parts compiled out (tools/parts.sh;
 //                                                   such a build emits no records: it is for kernel times and counters only)
 //     -DADSB_AMD_DIAG_BUILD=1 -DDIAG_ORDER_PARTS=n  the same for the ordering pass

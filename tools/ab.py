@@ -1,6 +1,6 @@
 """In-process A/B of kernel variants selected by environment knobs (read per submit): interleaved rounds, median kernel ms.
 
-    python tools/ab.py "lib=ab_libs/a.so" "lib=ab_libs/b.so" ...
+    python tools/ab.py "lib=ab_ship/a.so" "lib=ab_ship/b.so" ...
     AB_RATE=24 python tools/ab.py ...      the 2.4 MS/s mode and its workload
 """
 import os
@@ -14,7 +14,7 @@ import libadsb_amd as A  # noqa: E402
 from libadsb_amd import synth  # noqa: E402
 
 variants = [dict(kv.split("=") for kv in v.split(",") if kv) for v in sys.argv[1:]] or [{}]
-# a variant may name its own build of the library: lib=ab_libs/foo.so (see tools/build_variant.sh)
+# a variant may name its own build of the library: lib=ab_ship/foo.so (see tools/build_variant.sh)
 BB = A.REF_BUFFER_BYTES
 nbuf = 4096
 RATE = int(os.environ.get("AB_RATE", "20"))

@@ -1,5 +1,5 @@
 """kernel ms of library builds on three inputs (BASELINE, noise +-20, spacing 300), several contexts each, means.
-    python tools/ab_dense.py ab_libs/a.so ab_libs/b.so"""
+    python tools/ab_dense.py ab_ship/a.so ab_ship/b.so"""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,7 @@
 #!/bin/bash
-# tools/build_variant.sh <git-rev|WORK> <name>  -> ab_libs/<name>.so  (for in-process A/B of two builds)
+# tools/build_variant.sh <git-rev|WORK> <name>  -> $AB_OUT/<name>.so, AB_OUT=/tmp/ab_libs unless set  (for A/B of two builds)
+# The output lies OUTSIDE the repository on purpose: everything inside it travels to the GPU box with every gpurun call.  Copy the builds a
+# measurement needs into ab_ship/ (git-ignored) for that call, name them there (tools/uat_ab.py ab_ship/a.so ab_ship/b.so), delete them afterwards.
 set -e
 rev=$1; name=$2; root=$(cd "$(dirname "$0")/.." && pwd)
 tmp=$(mktemp -d)
@@ -14,5 +16,6 @@ for f in $srcs; do
   objs="$objs $tmp/$(basename $f).o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/ab_libs/$name.so $objs
-rm -rf $tmp; echo built ab_libs/$name.so
+out=${AB_OUT:-/tmp/ab_libs}; mkdir -p $out
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so $objs
+rm -rf $tmp; echo built $out/$name.so

@@ -1,9 +1,9 @@
 #!/bin/bash
-# tools/parts.sh : cost of scan1090_kernel by part -- builds with the later parts compiled out (ab_libs/part1..part4.so, made by
+# tools/parts.sh : cost of scan1090_kernel by part -- builds with the later parts compiled out (ab_ship/part1..part4.so, made by
 #   for k in 1 2 3; do EXTRA_FLAGS="-DADSB_AMD_DIAG_BUILD=1 -DDIAG_PARTS=$k" tools/build_variant.sh WORK part$k; done; tools/build_variant.sh WORK part4
 # on the build host), PMC instruction counts and kernel time of each on the 1 GiB bench workload.
 tools/pmc_ab.sh part1 part2 part3 part4 > gpurun_out/parts_pmc.txt 2>&1
-python3 tools/ab.py lib=ab_libs/part1.so lib=ab_libs/part2.so lib=ab_libs/part3.so lib=ab_libs/part4.so > gpurun_out/parts_time.txt 2>&1
+python3 tools/ab.py lib=ab_ship/part1.so lib=ab_ship/part2.so lib=ab_ship/part3.so lib=ab_ship/part4.so > gpurun_out/parts_time.txt 2>&1
 python3 - <<'PY'
 import re
 pmc = open("gpurun_out/parts_pmc.txt").read()

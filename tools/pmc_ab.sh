@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/pmc_ab.sh <name> [<name> ...] : SQ counters of scan1090_kernel for ab_libs/<name>.so (bench --serial, 3 steps, means per launch)
+# tools/pmc_ab.sh <name> [<name> ...] : SQ counters of scan1090_kernel for ab_ship/<name>.so (bench --serial, 3 steps, means per launch)
 # AB_BENCH_ARGS="--rate 24" AB_KERNEL=scan2400 for the 2.4 MS/s mode; AB_PASSES="1 2 3 4" adds FETCH_SIZE and WRITE_SIZE passes
 export TMPDIR=/tmp
 root=$PWD
@@ -11,7 +11,7 @@ for name in "$@"; do
     elif [ $pass = 5 ]; then ctr="SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES";
     else ctr="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD"; fi
     out=$root/gpurun_out/pmc_ab/$name.$pass; rm -rf $out; mkdir -p $out
-    (cd /tmp && ADSB_AMD_LIB=$root/${AB_DIR:-ab_libs}/$name.so rocprofv3 --pmc $ctr --output-format csv -d $out/p -- python3 $root/bench.py --steps 3 --warmup 1 --cpu-buffers 0 --serial --no-extras $AB_BENCH_ARGS > $out/log 2>&1)
+    (cd /tmp && ADSB_AMD_LIB=$root/${AB_DIR:-ab_ship}/$name.so rocprofv3 --pmc $ctr --output-format csv -d $out/p -- python3 $root/bench.py --steps 3 --warmup 1 --cpu-buffers 0 --serial --no-extras $AB_BENCH_ARGS > $out/log 2>&1)
   done
 done
 python3 - "$@" <<'PY'

@@ -1,6 +1,6 @@
 """Time line of the pipelined scan loop without a profiler: a measurement build (-DADSB_AMD_DIAG_BUILD=1 -DDIAG_STAMPS=1, diag.hip.h) lets every kernel note when its first wave came in
 and its last went out (100 MHz clock); this prints the steady-state averages of scan, gap, ordering pass, gap.
-    EXTRA_FLAGS="-DADSB_AMD_DIAG_BUILD=1 -DDIAG_STAMPS=1" tools/build_variant.sh WORK stamps && python tools/stamps.py ab_libs/stamps.so [timing_every]"""
+    EXTRA_FLAGS="-DADSB_AMD_DIAG_BUILD=1 -DDIAG_STAMPS=1" tools/build_variant.sh WORK stamps && python tools/stamps.py ab_ship/stamps.so [timing_every]"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,6 @@
 """When do the waves of one scan launch finish?  (measurement build: -DADSB_AMD_DIAG_BUILD=1 -DDIAG_STAMPS=1, diag.hip.h)  Per XCD (workgroup index % 8) and per work counter: the time of the
 last wave out, relative to the first wave in.
-    python tools/stamps_waves.py ab_libs/stamps.so"""
+    python tools/stamps_waves.py ab_ship/stamps.so"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

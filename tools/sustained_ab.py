@@ -1,6 +1,6 @@
 """Kernel ms of build variants in SUSTAINED operation (what bench.py measures): every variant runs its scans back to back over two
 slots for `seconds`, the median of the second half of the run is reported; variants one after the other with a pause.
-    python tools/sustained_ab.py ab_libs/a.so ab_libs/b.so ...     (AB_SECONDS=2)"""
+    python tools/sustained_ab.py ab_ship/a.so ab_ship/b.so ...     (AB_SECONDS=2)"""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

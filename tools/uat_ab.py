@@ -1,5 +1,5 @@
 """A/B of library builds on the UAT 978 workload: one bench.py process per build (ADSB_AMD_LIB), the same synthetic GiB.
-    python tools/uat_ab.py ab_libs/a.so ab_libs/b.so ...
+    python tools/uat_ab.py ab_ship/a.so ab_ship/b.so ...
 """
 import json
 import os

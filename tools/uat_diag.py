@@ -1,5 +1,5 @@
 """Where the demodulating wave's time goes: shader-clock cycles by phase and kind of match, from a measurement build (-DADSB_AMD_DIAG_BUILD=1 -DDIAG_UAT=1, diag.hip.h).
-    EXTRA_FLAGS="-DADSB_AMD_DIAG_BUILD=1 -DDIAG_UAT=1" tools/build_variant.sh WORK uat_diag && ADSB_AMD_LIB=ab_libs/uat_diag.so python tools/uat_diag.py [MiB]
+    EXTRA_FLAGS="-DADSB_AMD_DIAG_BUILD=1 -DDIAG_UAT=1" tools/build_variant.sh WORK uat_diag && ADSB_AMD_LIB=ab_ship/uat_diag.so python tools/uat_diag.py [MiB]
 Cycles are per wave (one wave per position), summed over the launch; the table gives the mean per position and the share of the total.
 """
 import ctypes as C
