@@ -151,6 +151,10 @@ struct adsb_amd_uat
     int         device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t  ev[6]  = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // What the demodulation pass leaves behind -- records, payloads, uplink payloads, the frames behind frames: 7 MB per GiB -- goes to the host on
+    // a stream of its own, beside the decision kernels instead of behind them (decide_and_fetch).
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t  ev_demod = nullptr, ev_counts = nullptr; // the demodulation pass is done; its counts are on the host
     std::string error;
 
     uint16_t*             lut_d = nullptr;
@@ -221,6 +225,9 @@ struct adsb_amd_uat
         if (counts_h) (void)hipHostFree(counts_h);
         for (auto e : ev)
             if (e) (void)hipEventDestroy(e);
+        if (ev_demod) (void)hipEventDestroy(ev_demod);
+        if (ev_counts) (void)hipEventDestroy(ev_counts);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -228,7 +235,10 @@ struct adsb_amd_uat
     {
         UAT_HIP(hipSetDevice(device));
         UAT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        UAT_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         for (auto& e : ev) UAT_HIP(hipEventCreate(&e));
+        UAT_HIP(hipEventCreateWithFlags(&ev_demod, hipEventDisableTiming));
+        UAT_HIP(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
         // InitATan2Table, UAT978.cpp:76-100
         lut_h.resize(65536);
         for (unsigned i = 0; i < 256; i++)
@@ -410,6 +420,7 @@ struct adsb_amd_uat
         UAT_HIP(hipEventRecord(ev[2], stream));
         UAT_HIP(launch_uat978_demod(d, count, true, stream));
         UAT_HIP(hipEventRecord(ev[3], stream));
+        UAT_HIP(hipEventRecord(ev_demod, stream));
         return ADSB_AMD_OK;
     }
 
@@ -421,45 +432,100 @@ struct adsb_amd_uat
         a.cand    = sorted_d;
         const bool     decide = a.lenbits > 0;
         const uint32_t mark_words = (count + 31) / 32;
-        if (decide)
-        {
-            UAT_HIP(marks_h.reserve(mark_words, 0));
-            UAT_HIP(hipEventRecord(ev[5], stream));
-            UAT_HIP(launch_uat978_decide(a, count, sorted_d, stream));
-            UAT_HIP(hipEventRecord(ev[4], stream));
-            UAT_HIP(hipMemcpyAsync(marks_h.p, marks_d, mark_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            UAT_HIP(hipMemcpyAsync(extras_h.p, extras_d, kExtraFirstCopy * sizeof(uat_extra_t), hipMemcpyDeviceToHost, stream));
-            UAT_HIP(hipMemcpyAsync(extra_pay_h.p, extra_pay_d, (size_t)kExtraFirstCopy * kUatPayloadStride, hipMemcpyDeviceToHost, stream));
+        if (in_pipeline)
+        { // Calls in flight: everything behind the decision kernels, on the call's own stream, one wait.  (The copies of the other form set out
+          // earlier but its counts -- sixteen bytes, which the runtime copies with a kernel -- have to get onto a chip that the other calls'
+          // scan and demodulation kernels fill, and the worker waits for them: pipelined step 0.44 -> 0.49 ms.)
+            if (decide)
+            {
+                UAT_HIP(marks_h.reserve(mark_words, 0));
+                UAT_HIP(hipEventRecord(ev[5], stream));
+                UAT_HIP(launch_uat978_decide(a, count, sorted_d, stream));
+                UAT_HIP(hipEventRecord(ev[4], stream));
+                UAT_HIP(hipMemcpyAsync(marks_h.p, marks_d, mark_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                UAT_HIP(hipMemcpyAsync(extras_h.p, extras_d, kExtraFirstCopy * sizeof(uat_extra_t), hipMemcpyDeviceToHost, stream));
+                UAT_HIP(hipMemcpyAsync(extra_pay_h.p, extra_pay_d, (size_t)kExtraFirstCopy * kUatPayloadStride, hipMemcpyDeviceToHost, stream));
+            }
+            UAT_HIP(hipMemcpyAsync(counts_h + 1, counts_d + 1, (kUatCountWords - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            UAT_HIP(hipMemcpyAsync(recs_h.p, recs_d, (size_t)count * sizeof(uat_rec_t), hipMemcpyDeviceToHost, stream));
+            UAT_HIP(hipMemcpyAsync(pay_h.p, pay_d, (size_t)count * kUatPayloadStride, hipMemcpyDeviceToHost, stream));
+            UAT_HIP(hipStreamSynchronize(stream));
+            const uint32_t up_total = counts_h[kUatCountUplinkSlots];
+            const bool     overflow = counts_h[kUatCountOverflow] != 0;
+            if (up_total > up_cap && !overflow) return fail(ADSB_AMD_EHIP, "UAT uplink payload area too small");
+            const uint32_t up_have = std::min(up_total, up_cap);
+            nextras                = std::min<uint32_t>(counts_h[kUatCountExtras], extra_cap);
+            decided                = decide && !overflow;
+            bool more              = false;
+            if (up_have > nuplink)
+            {
+                UAT_HIP(up_h.reserve((size_t)up_have * 432, (size_t)nuplink * 432));
+                UAT_HIP(hipMemcpyAsync(up_h.p + (size_t)nuplink * 432, up_d + (size_t)nuplink * 432, (size_t)(up_have - nuplink) * 432,
+                                       hipMemcpyDeviceToHost, stream));
+                nuplink = up_have, more = true;
+            }
+            if (decided && nextras > kExtraFirstCopy)
+            {
+                UAT_HIP(extras_h.reserve(nextras, kExtraFirstCopy));
+                UAT_HIP(extra_pay_h.reserve((size_t)nextras * kUatPayloadStride, (size_t)kExtraFirstCopy * kUatPayloadStride));
+                UAT_HIP(hipMemcpyAsync(extras_h.p + kExtraFirstCopy, extras_d + kExtraFirstCopy, (size_t)(nextras - kExtraFirstCopy) * sizeof(uat_extra_t),
+                                       hipMemcpyDeviceToHost, stream));
+                UAT_HIP(hipMemcpyAsync(extra_pay_h.p + (size_t)kExtraFirstCopy * kUatPayloadStride, extra_pay_d + (size_t)kExtraFirstCopy * kUatPayloadStride,
+                                       (size_t)(nextras - kExtraFirstCopy) * kUatPayloadStride, hipMemcpyDeviceToHost, stream));
+                more = true;
+            }
+            if (more) UAT_HIP(hipStreamSynchronize(stream));
         }
-        UAT_HIP(hipMemcpyAsync(counts_h + 1, counts_d + 1, (kUatCountWords - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        UAT_HIP(hipMemcpyAsync(recs_h.p, recs_d, (size_t)count * sizeof(uat_rec_t), hipMemcpyDeviceToHost, stream));
-        UAT_HIP(hipMemcpyAsync(pay_h.p, pay_d, (size_t)count * kUatPayloadStride, hipMemcpyDeviceToHost, stream));
-        UAT_HIP(hipStreamSynchronize(stream));
-        const uint32_t up_total = counts_h[kUatCountUplinkSlots];
-        const bool     overflow = counts_h[kUatCountOverflow] != 0;
-        if (up_total > up_cap && !overflow) return fail(ADSB_AMD_EHIP, "UAT uplink payload area too small");
-        const uint32_t up_have = std::min(up_total, up_cap);
-        nextras                = std::min<uint32_t>(counts_h[kUatCountExtras], extra_cap);
-        decided                = decide && !overflow;
-        bool more              = false;
-        if (up_have > nuplink)
-        {
-            UAT_HIP(up_h.reserve((size_t)up_have * 432, (size_t)nuplink * 432));
-            UAT_HIP(hipMemcpyAsync(up_h.p + (size_t)nuplink * 432, up_d + (size_t)nuplink * 432, (size_t)(up_have - nuplink) * 432,
-                                   hipMemcpyDeviceToHost, stream));
-            nuplink = up_have, more = true;
+        else
+        { // One call at a time: what the demodulation pass left behind sets out for the host beside the decision kernels (0.733 -> 0.675 ms per call).
+            // (1) behind the demodulation pass, on the copy stream: its counts first (they say how much more there is to fetch), then the records
+            // and the payloads.  The decision kernels read none of this and write none of it.
+            static_assert(kUatCountUplinkSlots == 1 && kUatCountOverflow == 4 && kUatCountFinalBit == 5 && kUatCountTaken == 6, "the two copies of the counts below");
+            UAT_HIP(hipStreamWaitEvent(copy_stream, ev_demod, 0));
+            UAT_HIP(hipMemcpyAsync(counts_h + kUatCountUplinkSlots, counts_d + kUatCountUplinkSlots, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, copy_stream));
+            UAT_HIP(hipEventRecord(ev_counts, copy_stream));
+            UAT_HIP(hipMemcpyAsync(recs_h.p, recs_d, (size_t)count * sizeof(uat_rec_t), hipMemcpyDeviceToHost, copy_stream));
+            UAT_HIP(hipMemcpyAsync(pay_h.p, pay_d, (size_t)count * kUatPayloadStride, hipMemcpyDeviceToHost, copy_stream));
+            if (decide)
+            {
+                UAT_HIP(hipMemcpyAsync(extras_h.p, extras_d, kExtraFirstCopy * sizeof(uat_extra_t), hipMemcpyDeviceToHost, copy_stream));
+                UAT_HIP(hipMemcpyAsync(extra_pay_h.p, extra_pay_d, (size_t)kExtraFirstCopy * kUatPayloadStride, hipMemcpyDeviceToHost, copy_stream));
+                // (2) the decisions, on the call's own stream, beside those copies
+                UAT_HIP(marks_h.reserve(mark_words, 0));
+                UAT_HIP(hipEventRecord(ev[5], stream));
+                UAT_HIP(launch_uat978_decide(a, count, sorted_d, stream));
+                UAT_HIP(hipEventRecord(ev[4], stream));
+                UAT_HIP(hipMemcpyAsync(marks_h.p, marks_d, mark_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                UAT_HIP(hipMemcpyAsync(counts_h + kUatCountFinalBit, counts_d + kUatCountFinalBit, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            }
+            // (3) as soon as the counts are here: the uplink payloads and the frames behind frames beyond the first copy, still beside the decisions
+            UAT_HIP(hipEventSynchronize(ev_counts));
+            const uint32_t up_total = counts_h[kUatCountUplinkSlots];
+            const bool     overflow = counts_h[kUatCountOverflow] != 0;
+            if (up_total > up_cap && !overflow) return fail(ADSB_AMD_EHIP, "UAT uplink payload area too small");
+            const uint32_t up_have = std::min(up_total, up_cap);
+            nextras                = std::min<uint32_t>(counts_h[kUatCountExtras], extra_cap);
+            decided                = decide && !overflow;
+            if (up_have > nuplink)
+            {
+                UAT_HIP(up_h.reserve((size_t)up_have * 432, (size_t)nuplink * 432));
+                UAT_HIP(hipMemcpyAsync(up_h.p + (size_t)nuplink * 432, up_d + (size_t)nuplink * 432, (size_t)(up_have - nuplink) * 432,
+                                       hipMemcpyDeviceToHost, copy_stream));
+                nuplink = up_have;
+            }
+            if (decided && nextras > kExtraFirstCopy)
+            {
+                UAT_HIP(hipStreamSynchronize(copy_stream)); // (the first copy is on its way into the arrays that grow here)
+                UAT_HIP(extras_h.reserve(nextras, kExtraFirstCopy));
+                UAT_HIP(extra_pay_h.reserve((size_t)nextras * kUatPayloadStride, (size_t)kExtraFirstCopy * kUatPayloadStride));
+                UAT_HIP(hipMemcpyAsync(extras_h.p + kExtraFirstCopy, extras_d + kExtraFirstCopy, (size_t)(nextras - kExtraFirstCopy) * sizeof(uat_extra_t),
+                                       hipMemcpyDeviceToHost, copy_stream));
+                UAT_HIP(hipMemcpyAsync(extra_pay_h.p + (size_t)kExtraFirstCopy * kUatPayloadStride, extra_pay_d + (size_t)kExtraFirstCopy * kUatPayloadStride,
+                                       (size_t)(nextras - kExtraFirstCopy) * kUatPayloadStride, hipMemcpyDeviceToHost, copy_stream));
+            }
+            UAT_HIP(hipStreamSynchronize(copy_stream));
+            UAT_HIP(hipStreamSynchronize(stream));
         }
-        if (decided && nextras > kExtraFirstCopy)
-        {
-            UAT_HIP(extras_h.reserve(nextras, kExtraFirstCopy));
-            UAT_HIP(extra_pay_h.reserve((size_t)nextras * kUatPayloadStride, (size_t)kExtraFirstCopy * kUatPayloadStride));
-            UAT_HIP(hipMemcpyAsync(extras_h.p + kExtraFirstCopy, extras_d + kExtraFirstCopy, (size_t)(nextras - kExtraFirstCopy) * sizeof(uat_extra_t),
-                                   hipMemcpyDeviceToHost, stream));
-            UAT_HIP(hipMemcpyAsync(extra_pay_h.p + (size_t)kExtraFirstCopy * kUatPayloadStride, extra_pay_d + (size_t)kExtraFirstCopy * kUatPayloadStride,
-                                   (size_t)(nextras - kExtraFirstCopy) * kUatPayloadStride, hipMemcpyDeviceToHost, stream));
-            more = true;
-        }
-        if (more) UAT_HIP(hipStreamSynchronize(stream));
         nrecords = count;
         UAT_HIP(hipEventElapsedTime(&demod_ms, ev[2], ev[3]));
         wall_ms[2] = 0.f;
@@ -781,6 +847,7 @@ struct adsb_amd_uat
     Job                           jobs[kSides];    // [0] runs on this object, [s] on twins[s - 1]
     uint64_t                      submitted = 0, collected = 0;
     bool                          pipe_stop = false;
+    bool                          in_pipeline = false; // this side is running a submitted call (decide_and_fetch)
 
     adsb_amd_uat* side(uint64_t k) { return (k % kSides) ? twins[k % kSides - 1].get() : this; }
 
@@ -799,7 +866,9 @@ struct adsb_amd_uat
                 pipe_cv.wait(lk, [&] { return pipe_stop || j->queued; });
                 if (pipe_stop) return;
             }
+            side((uint64_t)s)->in_pipeline = true;
             const int rc = device_ok ? side((uint64_t)s)->scan(j->in, j->n, false) : side((uint64_t)s)->fail(ADSB_AMD_EHIP, "hipSetDevice failed on a pipeline worker");
+            side((uint64_t)s)->in_pipeline = false;
             {
                 std::lock_guard<std::mutex> lk(pipe_mu);
                 j->rc = rc, j->queued = false, j->done = true;
