@@ -11,13 +11,14 @@
 //                          wrapped 16-bit differences, sign bits, both 18-bit check words -- bound by the HBM read (2 B/sample)
 //   uat_sign_kernel +      the same two steps for a buffer of *phases* (the process_buffer seam and the 65 536-entry staging
 //   uat_match_kernel       rounds of HandleData; small inputs)
-//   uat_demod_kernel       one wave per match (the host may also ask for further sample indices, see uat978_host.cpp): one coalesced
-//                          burst stages the phase differences of the match's samples in LDS (ten tiles for an uplink frame), then
+//   uat_demod_kernel       one wave per match (the host may also ask for further sample indices, see uat978_host.cpp), twelve waves to a
+//                          workgroup that shares one quadrant of the phase LUT in LDS (the table's symmetries give the rest exactly):
+//                          one coalesced burst stages the phase differences of the match's samples in LDS (ten tiles for an uplink frame), then
 //                          the 36-bit sync re-check against the data-derived centre for the match and, when that one needed
 //                          corrections, for the next sample (the reference tries both and keeps the better), the frame sliced a
 //                          byte per lane at that centre, its syndromes with the wave across the symbols and its Reed-Solomon
-//                          decode with the whole wave on one code word (rs978.h: Berlekamp-Massey, Chien, Forney with libfec's
-//                          conventions); the choice between the two alignments is made here; and the frames the scan loop would take
+//                          decode with the whole wave on one code word (rs978.h: the locator by elimination for the two ADS-B codes,
+//                          Berlekamp-Massey otherwise, Chien, Forney with libfec's conventions); the choice between the two alignments is made here; and the frames the scan loop would take
 //                          behind this one through stale register bits (StaleWindow), by the same wave.  A record is 32 bytes, the
 //                          corrected ADS-B frame bytes go to a parallel array
 //   uat_order_*            counting sort of the matches by stream position, on the device; also lists the uplink matches, which the
@@ -1730,8 +1731,8 @@ __global__ __launch_bounds__(kUatDecideThreads) void uat_mark_kernel(uint32_t n,
     // The bit map of this block's matches is put together in LDS and goes out with one atomic per word: device-scope atomics are
     // performed past the XCD's L2 (one per frame taken, 74 000 per GiB, made this kernel 64 us long).  A start bit's second match
     // can be the first match of the next block, hence one word more than the block has, and atomics rather than stores.
-    // (It lives where the hop tables were -- nobody reads them after the last level: 20 480 bytes in all, which is what seven demodulating
-    // waves per SIMD leave free on a CU, so this workgroup can run beside another call's demodulation kernel.)
+    // (It lives where the hop tables were -- nobody reads them after the last level: 20 480 bytes in all, which fits beside a scan kernel's
+    // workgroup on a CU.  Round 4's demodulation kernel left that much free too; round 5's takes the whole LDS while it runs.)
     uint32_t* const map = reinterpret_cast<uint32_t*>(&hop[0][0]);
     static_assert(sizeof(hop) >= (kUatDecideNodes / 32 + 1) * sizeof(uint32_t), "the bit map fits where the tables were");
     if (threadIdx.x < kUatDecideNodes / 32 + 1) map[threadIdx.x] = 0;
