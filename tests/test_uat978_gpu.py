@@ -138,6 +138,24 @@ def test_reference_seam_process_buffer(native_libs):
         L.adsb_amd_uat_set_dump_raw_message(None)
 
 
+@pytest.mark.parametrize("over", [
+    {"amp_lo": 110, "amp_hi": 127, "noise_amp": 30},                      # clipping at 0 and 255 on most frames
+    {"amp_lo": 126, "amp_hi": 127, "noise_amp": 60, "pct_uplink": 40},    # nearly every sample of a frame clipped somewhere on the way round
+    {"amp_lo": 2, "amp_hi": 5, "noise_amp": 1, "mean_gap_bits": 200},     # everything within a few LSB of the centre (127 / 128)
+])
+def test_iq_path_at_full_scale_and_at_the_centre(uat, over):
+    """The batch path looks its phases up in one quadrant of the table and derives the rest (uat978.hip, lut2_folded): the coordinates 0 and
+    255 (the fold's far edge) and 127 / 128 (its seam) are where a wrong fold would show.  Frames == the oracle's on the whole table."""
+    cfg = synth.default_cfg978(**over)
+    iq = synth.fill978(77, 16 * 1024 * 1024, cfg)
+    b = iq.reshape(-1, 2)
+    if over["amp_hi"] >= 127:
+        assert int((b == 0).sum()) > 1000 and int((b == 255).sum()) > 1000
+    want = O.process_buffer978(O.phase_lut978()[iq.view(np.uint16)])
+    assert uat.process_iq(iq) == want
+    assert len(want[0]) > 100
+
+
 def test_device_resident_input(uat):
     import torch
     iq = synth.fill978(13, 8 * 1024 * 1024, synth.default_cfg978())
