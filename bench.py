@@ -65,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--noise", type=int, default=None, help="N = 1: background noise amplitude of the synthetic input (default 3, the BASELINE workload; "
                     "any other value is a sensitivity run, labelled as such: profiles/r05_sensitivity.txt)")
     ap.add_argument("--spacing", type=int, default=None, help="N = 1: mean frame start-to-start spacing in samples (default 2000)")
+    ap.add_argument("--rotate", type=int, default=1, help="N = 1: K distinct device-resident inputs of --mib each (generator buffers k * nbuf ...), step i scans "
+                    "input i mod K: nothing a step reads was read by the K - 1 steps before it, so neither the L2s nor the 256 MiB memory-side cache "
+                    "can serve it (K = 1, the default, rescans one resident input; profiles/r06_rotate.txt holds the A/B)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the end_to_end and uat978 blocks (profiling runs)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N > 1 ranks all on cuda:0 with the gloo backend: exercises the "
                     "multi-rank code path (sharding, record gather, resolve) on a one-GPU box; the numbers mean nothing")
@@ -231,7 +234,15 @@ def main():
 
 
 def make_runner(args, sc, d_iq, BB, stream):
-    nbytes = d_iq.numel()
+    inputs = d_iq if isinstance(d_iq, (list, tuple)) else [d_iq]  # --rotate K: step i scans inputs[i mod K]
+    nbytes = inputs[0].numel()
+    seen = [0]  # steps submitted so far by this runner (the rotation goes on across calls of run)
+    made = [0, 0]  # records delivered, steps delivered (the inputs of a rotation differ in their record counts)
+
+    def ptr():
+        p = inputs[seen[0] % len(inputs)].data_ptr()
+        seen[0] += 1
+        return p
 
     def run(steps):
         """`steps` pipelined steps, each delivering the sorted records with their decoded fields to the host in the packed hand-over
@@ -246,20 +257,25 @@ def make_runner(args, sc, d_iq, BB, stream):
                 acc[0] += tm[0]
                 acc[1] += 1
                 acc[2] += tm[1]
+        def took(r):
+            made[0] += len(r)
+            made[1] += 1
+            return r
         if args.serial:
             for i in range(steps):
-                sc.submit(d_iq.data_ptr(), nbytes, BB, stream, 0)
-                rec = sc.fetch_packed(0, copy=False)
+                sc.submit(ptr(), nbytes, BB, stream, 0)
+                rec = took(sc.fetch_packed(0, copy=False))
                 note(0)
             return rec, acc[0], acc[1], acc[2]
-        sc.submit(d_iq.data_ptr(), nbytes, BB, stream, 0)
+        sc.submit(ptr(), nbytes, BB, stream, 0)
         for i in range(1, steps):
-            sc.submit(d_iq.data_ptr(), nbytes, BB, stream, i & 1)
-            rec = sc.fetch_packed((i - 1) & 1, copy=False)
+            sc.submit(ptr(), nbytes, BB, stream, i & 1)
+            rec = took(sc.fetch_packed((i - 1) & 1, copy=False))
             note((i - 1) & 1)
-        rec = sc.fetch_packed((steps - 1) & 1, copy=False)
+        rec = took(sc.fetch_packed((steps - 1) & 1, copy=False))
         note((steps - 1) & 1)
         return rec, acc[0], acc[1], acc[2]
+    run.delivered = made
     return run
 
 
@@ -274,12 +290,20 @@ def bench_1090_single(args, local_rank, A, synth, torch):
         args.no_extras = True  # the other blocks are defined on the BASELINE workload
         args.cpu_buffers = 0
     d_iq = torch.from_numpy(iq_host).cuda()
+    rotation = [d_iq]
+    for k in range(1, max(1, args.rotate)):  # --rotate K: K - 1 further inputs of the same generator, the buffers behind the first nbuf
+        more, _ = synth.fill_range(k * nbuf, nbuf, nthreads=ncpu, rate_x10=args.rate, cfg=synth.default_cfg(**over) if over else None)
+        rotation.append(torch.from_numpy(more).cuda())
+        del more
+    if args.rotate > 1:
+        args.no_extras = True  # an A/B of the headline kernel, not the headline line
+        args.cpu_buffers = 0
     torch.cuda.synchronize()
     sc = A.Scanner(local_rank, mode=args.rate)
     sc.set_outputs(A.OUT_PACKED)  # the throughput path hands over record head + decoded fields, 32 bytes, no message bytes
     stream = torch.cuda.current_stream().cuda_stream
     nbytes = d_iq.numel()
-    run = make_runner(args, sc, d_iq, BB, stream)
+    run = make_runner(args, sc, rotation, BB, stream)
     if args.rate != 20:
         args.no_extras = True  # end-to-end and CPU legs are defined on the parity-green workload only
         args.cpu_buffers = 0
@@ -297,6 +321,7 @@ def bench_1090_single(args, local_rank, A, synth, torch):
         run(args.warmup)
     sc.set_timing(args.time_every)  # (counts from here: the first launch of the timed region carries events, then every n-th)
     torch.cuda.synchronize()
+    run.delivered[0] = run.delivered[1] = 0
     t0 = time.perf_counter()
     rec, k_ms, k_n, t_ms = run(args.steps)
     torch.cuda.synchronize()
@@ -304,11 +329,12 @@ def bench_1090_single(args, local_rank, A, synth, torch):
     if k_n == 0:
         raise SystemExit("--time-every %d leaves no timed launch among %d steps" % (args.time_every, args.steps))
     nrec = int(len(rec))
+    nrec_mean = run.delivered[0] / max(1, run.delivered[1])  # == nrec unless --rotate K > 1 (the K inputs hold different frames)
     rec = rec.view(np.uint8).copy().view(rec.dtype)  # a byte copy (numpy copies a structured array field by field)
 
     samples = nbytes // 2
     kernel_ms = k_ms / k_n
-    alg_bytes = 2.0 * samples + 32.0 * nrec
+    alg_bytes = 2.0 * samples + 32.0 * nrec_mean
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     # host half on the records of one step: accepted frames -> msgs/s (no listener; with a native counting listener: end_to_end)
     # One resolver, the step's records fed six times as six consecutive stretches of the stream (a long-running handler: its helper
@@ -353,7 +379,9 @@ def bench_1090_single(args, local_rank, A, synth, torch):
                                 "2.4 MS/s mode: packed gate, five-phase preamble correlation, overlap-weighted Manchester slicing, CRC-24 + 1-bit "
                                 "repair; kernel == oracle/oracle2400.c in the GPU tests" % args.mib),
                    "sample_rate_x10": args.rate,
-                   "bytes_per_gpu": nbytes, "buffers_per_gpu": nbuf, "sharding": "one GPU", "pipelined": not args.serial},
+                   "bytes_per_gpu": nbytes, "buffers_per_gpu": nbuf, "sharding": "one GPU", "pipelined": not args.serial,
+                   "rotate": {"inputs": len(rotation), "what": "step i scans device-resident input i mod K (K x %d MiB, generator buffers k * %d ...)" % (args.mib, nbuf),
+                              "records_per_step_mean": round(nrec_mean, 1)} if len(rotation) > 1 else None},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(nbytes if args.rate == 20 else "mode2400:%d" % nbytes),
                      "kernel": "scan1090_kernel" if args.rate == 20 else "scan2400_kernel", "kernel_ms": round(kernel_ms, 4),
