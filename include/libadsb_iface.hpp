@@ -63,7 +63,9 @@ struct IDataProvider
     virtual void NotifySelfLocation(IAirCraft const&) = 0;
 };
 
-// State record the traffic manager owns; only the members a listener can reach through IAirCraft are kept here.
+// State record the traffic manager owns: the reference's members in the reference's order (AircraftImpl.h:26-44), so that the object has the same
+// size and every member the same offset under either header (held equal at compile time by tests/cpp/iface_matches_reference.cpp).  The six cpr*
+// members are the reference demodulator's scratch for its even/odd pair; the GPU handler keeps that state in its resolver and leaves them untouched.
 struct AirCraftImpl : IAirCraft
 {
     [[nodiscard]] Source           SourceId() const override { return sourceId; }
@@ -89,6 +91,12 @@ struct AirCraftImpl : IAirCraft
     int32_t             vertRate{};
     int32_t             lat1E7{};
     int32_t             lon1E7{};
+    double              cprOddLat{};
+    double              cprOddLon{};
+    time_point          cprOddTime{};
+    double              cprEvenLat{};
+    double              cprEvenLon{};
+    time_point          cprEvenTime{};
     Source              sourceId{};
 };
 
