@@ -31,7 +31,9 @@ struct uat_rec_t
     uint32_t slot;        // uplink: 432-byte slot of the decoded payload in the side array
 };
 static_assert(sizeof(uat_rec_t) == 32, "record layout");
-constexpr uint32_t kUatPayloadStride = 40; // ADS-B: corrected frame bytes 0..33 (18 of them for a short frame: skip == 276)
+constexpr uint32_t kUatPayloadStride = 40; // ADS-B: corrected frame bytes 0..33 (18 of them for a short frame: skip == 276), 
+// The matches of a stream, binned by position while they are found (round 6): bin = sample index >> kUatBinShift, kUatBinCap slots each.
+constexpr uint32_t kUatBinShift = 15, kUatBinCap = 16;
 
 // A frame the scan loop reaches only through stale register bits in the 17 bits after a jump: its position need not be a match of
 // the stream, so it is not in the match list.  The wave that demodulated the frame before it (`parent`, a position in the ordered
@@ -55,6 +57,7 @@ enum UatCount : uint32_t
     kUatCountOverflow,     // != 0: an extra or its payload slot did not fit; the decisions below are not valid
     kUatCountFinalBit,     // the largest `next bit` over the frames the loop takes
     kUatCountTaken,        // frames of the match list the loop takes
+    kUatCountBinOverflow,  // != 0: some bin of the match search held more than kUatBinCap matches: the bins are not the list, order the list itself
     kUatCountWords = 16
 };
 
@@ -93,12 +96,22 @@ struct UatArgs
     uint32_t*       exit_of;   // the first match outside the node's block of kUatDecideNodes on that path
     uint32_t*       emit_of;   // the match whose frame the loop takes at this start bit, kUatEnd = none
     uint32_t*       marks;     // bit per match: the loop takes its frame
+    // the bins of the match search (IQ input): fill counts of this call, the array the ordering pass zeroes for the next call (the two swap
+    // roles per call), how many words each of the two holds, and kUatBinCap slots per bin
+    uint32_t*       bin_fill;
+    uint32_t*       bin_fill_next;
+    uint32_t        bins_cap;
+    uint32_t*       bin_slots;
 };
 constexpr uint32_t kUatDecideNodes = 4096;
 
 hipError_t launch_uat978(const UatArgs& a, hipStream_t stream);                       // signs + 18-bit match
 hipError_t launch_uat978_order(const UatArgs& a, uint32_t ncand, uint32_t* scratch, uint32_t* sorted, hipStream_t stream);
+// the same from the bins the match search filled (a.bin_fill / a.bin_slots; no bin ran over): one launch
+hipError_t launch_uat978_order_bins(const UatArgs& a, uint32_t ncand, uint32_t* sorted, hipStream_t stream);
 hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, bool ordered, hipStream_t stream); // one wave per candidate
-hipError_t launch_uat978_decide(const UatArgs& a, uint32_t ncand, const uint32_t* sorted, hipStream_t stream); // which frames the loop takes
+// which frames the loop takes.  wide: workgroups of 1024 threads (a call that has the chip to itself) instead of 256 (calls in flight: four waves
+// find room beside another call's demodulation pass, sixteen wait for it)
+hipError_t launch_uat978_decide(const UatArgs& a, uint32_t ncand, const uint32_t* sorted, hipStream_t stream, bool wide);
 hipError_t launch_uat978_rs_selftest(const RsTables* tables, int kind, uint8_t* words, int* results, int count, hipStream_t stream);
 } // namespace adsb_amd

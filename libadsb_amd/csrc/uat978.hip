@@ -203,6 +203,15 @@ __device__ __forceinline__ uint32_t table_offset_hi(uint32_t y)
     return r;
 }
 
+// a match word into the bin of its stretch of the stream (see uat_scan_iq_kernel); counts = the call's UatCount words
+__device__ __forceinline__ void place_in_bin(uint32_t* __restrict__ bin_fill, uint32_t* __restrict__ bin_slots, uint32_t* __restrict__ counts, uint32_t value)
+{
+    const uint32_t bin = (value & 0x7FFFFFFFu) >> kUatBinShift;
+    const uint32_t at  = atomicAdd(&bin_fill[bin], 1u);
+    if (at < kUatBinCap) bin_slots[(size_t)bin * kUatBinCap + at] = value;
+    else atomicOr(&counts[kUatCountBinOverflow], 1u);
+}
+
 __device__ __forceinline__ uint32_t lut2(const uint16_t* __restrict__ lut_s, uint32_t iq2)
 { // phases of the two samples in one dword, packed the same way
     const uint32_t y  = swz2(iq2);
@@ -226,9 +235,14 @@ __device__ __forceinline__ uint8_t sign_byte_guarded(const uint16_t* __restrict_
     return (uint8_t)byte;
 }
 
+// bin_fill / bin_slots (round 6; null: not kept): besides the list, every match is placed in the bin of its 32 768-sample stretch of the stream --
+// kUatBinCap slots per bin, handed out by an atomic on the bin's fill count -- so that the ordering is ONE launch afterwards (uat_order_bins_kernel:
+// a prefix over the fill counts and a sorting network per bin) instead of the four of the counting sort over the list.  A bin that runs over
+// (dense noise that looks like check words, a constructed input) raises count[kUatCountBinOverflow]; the host then orders the list the old way.
 __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint16_t* __restrict__ iq, const uint16_t* __restrict__ lut,
                                                                       uint64_t n, uint32_t* __restrict__ cand, uint32_t cap,
-                                                                      uint32_t* __restrict__ count)
+                                                                      uint32_t* __restrict__ count, uint32_t* __restrict__ bin_fill,
+                                                                      uint32_t* __restrict__ bin_slots)
 {
     // The workgroup shares only the (read-only) table.  Each wave owns whole 2 048-sample spans: it produces the span's sign
     // bits plus 64 samples of halo into its own corner of LDS and searches them itself, so after the table is loaded no
@@ -263,7 +277,11 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
         if (lane == 0) base = atomicAdd(count, pending);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         for (uint32_t k = lane; k < pending; k += 64)
-            if (base + k < cap) cand[base + k] = my_parked[k];
+        {
+            const uint32_t value = my_parked[k];
+            if (base + k < cap) cand[base + k] = value;
+            if (bin_fill) place_in_bin(bin_fill, bin_slots, count, value);
+        }
         wave_lds_fence();
         if (lane == 0) parked_count[wave] = 0;
         wave_lds_fence();
@@ -359,6 +377,7 @@ __global__ __launch_bounds__(kUatScanThreads) void uat_scan_iq_kernel(const uint
                     { // more matches in one span than the parking area holds: straight to the global list
                         const uint32_t slot = atomicAdd(count, 1u);
                         if (slot < cap) cand[slot] = value;
+                        if (bin_fill) place_in_bin(bin_fill, bin_slots, count, value);
                     }
                 }
             }
@@ -930,7 +949,11 @@ __device__ __noinline__ int rs_decode_lds(lds_cu8 exp_t, lds_cu8 log_t, int nr, 
     if (lane <= nr) w.lambda[lane] = (uint8_t)lam;
     wave_fence();
 
-    // Chien search: X^-1 = alpha^i for i = 1 .. 255, four per lane; the coefficient and its logarithm are fetched once for the four
+    // Chien search: X^-1 = alpha^i for i = 1 .. 255, four per lane; the coefficient and its logarithm are fetched once for the four.
+    // (Round 6 measured the field elements of the code word's own positions first -- a lane's fourth element for the two ADS-B words, third and fourth for
+    // an uplink block; deg roots there are all there are -- and the rest only when roots are missing: the kernel went from 0.2008 to 0.2125 ms.  The
+    // words that gain are the correctable ones with errors, a quarter of the frames; every short frame's failing long-code attempt, 29 % of them,
+    // evaluates in two passes instead of one.  profiles/r06_uat978_variants.txt)
     int      count = 0;
     uint32_t q4[4] = {1, 1, 1, 1};
     for (int j = 1; j <= deg; j++)
@@ -1598,6 +1621,107 @@ __global__ __launch_bounds__(256) void uat_order_within_kernel(const uint32_t* _
     }
 }
 
+// ---- Round 6: the ordering as ONE launch, from the bins the match search filled (uat_scan_iq_kernel: place_in_bin).  A thread takes one bin:
+// the matches of all earlier bins (a sum over the fill counts: the earlier workgroups' by every workgroup for itself, 15 coalesced loads a thread
+// at most per GiB; its own by a prefix sum), its <= kUatBinCap matches through a sorting network in registers (Batcher's odd-even merge sort, 63
+// compare-exchanges on the match word rotated left by one, so that the order is by sample index), one run of stores.  It also lists the uplink
+// matches (which the demodulation takes first), zeroes the demodulation's work counters and the OTHER fill-count array, which the next call fills
+// (the two swap roles per call: this call's counts are still being summed by the later workgroups while the earlier ones are done).
+struct BatcherPairs
+{
+    uint8_t a[64], b[64];
+    int     n = 0;
+    constexpr BatcherPairs()
+        : a(), b()
+    {
+        for (int p = 1; p < (int)kUatBinCap; p <<= 1)
+            for (int k = p; k >= 1; k >>= 1)
+                for (int j = k % p; j + k < (int)kUatBinCap; j += 2 * k)
+                    for (int i = 0; i < k && i + j + k < (int)kUatBinCap; i++)
+                        if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) a[n] = (uint8_t)(i + j), b[n] = (uint8_t)(i + j + k), n++;
+    }
+};
+constexpr BatcherPairs kBatcher{};
+static_assert(kUatBinCap == 16 && kBatcher.n == 63, "Batcher's network for sixteen");
+constexpr int kUatBinThreads = 1024;
+
+__global__ __launch_bounds__(kUatBinThreads) void uat_order_bins_kernel(const uint32_t* __restrict__ bin_fill, uint32_t* __restrict__ bin_fill_next, uint32_t bins_cap,
+                                                                        const uint32_t* __restrict__ bin_slots, uint32_t nbins, uint32_t* __restrict__ sorted,
+                                                                        uint32_t cap, uint32_t* __restrict__ up_list, uint32_t* __restrict__ up_count,
+                                                                        uint32_t* __restrict__ demod_work)
+{
+    __shared__ uint32_t wave_before[kUatBinThreads / 64], wave_count[kUatBinThreads / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    if (blockIdx.x == 0 && t < kUatDemodRanges) demod_work[t * 32u] = 0; // the demodulation pass that follows starts from zero
+    for (uint32_t k = blockIdx.x * kUatBinThreads + t; k < bins_cap; k += gridDim.x * kUatBinThreads) bin_fill_next[k] = 0;
+    const uint32_t bin0 = blockIdx.x * kUatBinThreads, bin = bin0 + t;
+    uint32_t       before = 0;
+    for (uint32_t b = t; b < bin0; b += kUatBinThreads) before += bin_fill[b]; // (no bin ran over, or the host would not have launched this)
+    uint32_t n = bin < nbins ? bin_fill[bin] : 0u;
+    n          = n < kUatBinCap ? n : kUatBinCap;
+    // the bin's matches, rotated so that an unsigned comparison orders them by sample index; empty slots sort last
+    uint32_t v[kUatBinCap];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(bin_slots + (size_t)(bin < nbins ? bin : 0u) * kUatBinCap);
+#pragma unroll
+        for (uint32_t q = 0; q < kUatBinCap / 4; q++)
+        {
+            const uint4 x = 4 * q < n ? src[q] : make_uint4(0, 0, 0, 0);
+            v[4 * q] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kUatBinCap; i++) v[i] = i < n ? ((v[i] << 1) | (v[i] >> 31)) : 0xFFFFFFFFu; // (no match word is all ones)
+    }
+    // prefix sums: waves first, then the sixteen wave totals
+    uint32_t incl = n, binc = before;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1)
+    {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += up;
+        binc += (uint32_t)__shfl_xor((int)binc, d, 64);
+    }
+    if (lane == 63) wave_count[wave] = incl, wave_before[wave] = binc;
+    __syncthreads();
+    uint32_t pos = incl - n;
+#pragma unroll
+    for (uint32_t w = 0; w < kUatBinThreads / 64; w++) pos += wave_before[w] + (w < wave ? wave_count[w] : 0u);
+    if (__ballot(n > 1) != 0)
+    {
+#pragma unroll
+        for (int k = 0; k < kBatcher.n; k++)
+        {
+            const uint32_t lo = v[kBatcher.a[k]] < v[kBatcher.b[k]] ? v[kBatcher.a[k]] : v[kBatcher.b[k]];
+            const uint32_t hi = v[kBatcher.a[k]] < v[kBatcher.b[k]] ? v[kBatcher.b[k]] : v[kBatcher.a[k]];
+            v[kBatcher.a[k]] = lo, v[kBatcher.b[k]] = hi;
+        }
+    }
+    uint32_t ups = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kUatBinCap; i++)
+        if (i < n)
+        {
+            if (pos + i < cap) sorted[pos + i] = (v[i] >> 1) | (v[i] << 31);
+            ups += v[i] & 1u;
+        }
+    // positions of the uplink matches, one reservation per wave (as uat_order_within_kernel)
+    uint32_t uincl = ups;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1)
+    {
+        const uint32_t up = (uint32_t)__shfl_up((int)uincl, d, 64);
+        if (lane >= d) uincl += up;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)uincl, 63);
+    if (total == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(up_count, total);
+    uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + uincl - ups;
+#pragma unroll
+    for (uint32_t i = 0; i < kUatBinCap; i++)
+        if (i < n && (v[i] & 1u) && pos + i < cap) up_list[slot++] = pos + i;
+}
+
 // ---- which frames the scan loop takes.  The loop is sequential -- at the first match it reaches with clean registers it takes the
 // frame if one decodes there and jumps (next_bit, which the demodulating wave worked out including any frames behind it), else it
 // moves one bit on -- but what it does at a start bit does not depend on how it got there, so the rule is a successor function over
@@ -1609,7 +1733,8 @@ __global__ __launch_bounds__(256) void uat_order_within_kernel(const uint32_t* _
 // Threads of a decision workgroup (4096 nodes each).  256 since round 4: with calls in flight the 1024-thread form waited for sixteen free wave
 // slots on one CU beside a demodulation kernel that fills every SIMD (13 -> 98 us resident); four waves find room.  Pipelined step 0.540-0.545 ->
 // 0.523-0.527 ms, calls back to back 0.750-0.754 -> 0.788-0.794 (the kernels themselves are slower with a quarter of the lanes).
-constexpr int kUatDecideThreads = 256, kUatDecideLevels = 12, kUatNodesPerLane = (int)kUatDecideNodes / kUatDecideThreads;
+// Round 6: the width is the caller's choice -- 1024 threads for a call that has the chip to itself (13 + 20 us for the two kernels instead of 38 + 35).
+constexpr int kUatDecideLevels = 12;
 static_assert((1u << kUatDecideLevels) == kUatDecideNodes, "2^levels successors cover a block");
 constexpr uint32_t kIndexMask = 0x7FFFFFFFu;
 
@@ -1628,12 +1753,15 @@ __device__ __forceinline__ uint32_t first_at_or_after(const uint32_t* __restrict
     return lo;
 }
 
+template <int kUatDecideThreads>
 __global__ __launch_bounds__(kUatDecideThreads) void uat_succ_kernel(const uint32_t* __restrict__ sorted, uint32_t n, const uint32_t* __restrict__ next_bit,
                                                                      int64_t lenbits, int64_t first_bit, int64_t end_bit, uint32_t* __restrict__ succ,
                                                                      uint32_t* __restrict__ exit_of, uint32_t* __restrict__ emit_of, uint32_t* __restrict__ marks)
 {
+    constexpr int kUatNodesPerLane = (int)kUatDecideNodes / kUatDecideThreads;
     __shared__ uint32_t nxt[kUatDecideNodes];
     const uint32_t      base = blockIdx.x * kUatDecideNodes;
+    static_assert(kUatDecideThreads >= (int)kUatDecideNodes / 32 + 1, "a thread per word of the block's bit map");
     if (threadIdx.x < kUatDecideNodes / 32 && base + 32u * threadIdx.x < n) marks[base / 32 + threadIdx.x] = 0; // uat_mark_kernel ORs into it
 #pragma unroll
     for (int j = 0; j < kUatNodesPerLane; j++)
@@ -1689,10 +1817,12 @@ __global__ __launch_bounds__(kUatDecideThreads) void uat_succ_kernel(const uint3
     }
 }
 
+template <int kUatDecideThreads>
 __global__ __launch_bounds__(kUatDecideThreads) void uat_mark_kernel(uint32_t n, const uint32_t* __restrict__ succ, const uint32_t* __restrict__ exit_of,
                                                                      const uint32_t* __restrict__ emit_of, const uint32_t* __restrict__ next_bit,
                                                                      uint32_t* __restrict__ marks, uint32_t* __restrict__ counts)
 {
+    constexpr int      kUatNodesPerLane = (int)kUatDecideNodes / kUatDecideThreads;
     constexpr uint16_t kOut = 0xFFFFu;
     __shared__ uint16_t hop[2][kUatDecideNodes]; // hop[l & 1][i]: the node 2^l steps after i, kOut = outside the block
     __shared__ uint8_t  on_path[kUatDecideNodes];
@@ -1768,12 +1898,20 @@ __global__ __launch_bounds__(kUatDecideThreads) void uat_mark_kernel(uint32_t n,
 
 } // namespace
 
-hipError_t launch_uat978_decide(const UatArgs& a, uint32_t ncand, const uint32_t* sorted, hipStream_t stream)
+hipError_t launch_uat978_decide(const UatArgs& a, uint32_t ncand, const uint32_t* sorted, hipStream_t stream, bool wide)
 {
     if (ncand == 0 || a.lenbits <= 0) return hipSuccess;
     const uint32_t blocks = (ncand + kUatDecideNodes - 1) / kUatDecideNodes;
-    hipLaunchKernelGGL(uat_succ_kernel, dim3(blocks), dim3(kUatDecideThreads), 0, stream, sorted, ncand, a.next_bit, a.lenbits, a.first_bit, a.end_bit, a.succ, a.exit_of, a.emit_of, a.marks);
-    hipLaunchKernelGGL(uat_mark_kernel, dim3(blocks), dim3(kUatDecideThreads), 0, stream, ncand, a.succ, a.exit_of, a.emit_of, a.next_bit, a.marks, a.counts);
+    if (wide)
+    {
+        hipLaunchKernelGGL(uat_succ_kernel<1024>, dim3(blocks), dim3(1024), 0, stream, sorted, ncand, a.next_bit, a.lenbits, a.first_bit, a.end_bit, a.succ, a.exit_of, a.emit_of, a.marks);
+        hipLaunchKernelGGL(uat_mark_kernel<1024>, dim3(blocks), dim3(1024), 0, stream, ncand, a.succ, a.exit_of, a.emit_of, a.next_bit, a.marks, a.counts);
+    }
+    else
+    {
+        hipLaunchKernelGGL(uat_succ_kernel<256>, dim3(blocks), dim3(256), 0, stream, sorted, ncand, a.next_bit, a.lenbits, a.first_bit, a.end_bit, a.succ, a.exit_of, a.emit_of, a.marks);
+        hipLaunchKernelGGL(uat_mark_kernel<256>, dim3(blocks), dim3(256), 0, stream, ncand, a.succ, a.exit_of, a.emit_of, a.next_bit, a.marks, a.counts);
+    }
     return hipGetLastError();
 }
 
@@ -1786,7 +1924,7 @@ hipError_t launch_uat978(const UatArgs& a, hipStream_t stream)
     {
         const uint64_t nwgs = ((a.nsamples + kUatWaveSamples - 1) / kUatWaveSamples + kUatScanWaves - 1) / kUatScanWaves;
         const uint32_t grid = (uint32_t)(nwgs < 256 ? nwgs : 256); // one workgroup per CU (its LDS footprint allows no more)
-        hipLaunchKernelGGL(uat_scan_iq_kernel, dim3(grid), dim3(kUatScanThreads), 0, stream, a.in, a.lut, a.nsamples, a.cand, a.cand_cap, a.counts);
+        hipLaunchKernelGGL(uat_scan_iq_kernel, dim3(grid), dim3(kUatScanThreads), 0, stream, a.in, a.lut, a.nsamples, a.cand, a.cand_cap, a.counts, a.bin_fill, a.bin_slots);
         return hipGetLastError();
     }
     const uint64_t nwords = (a.nsamples + 63) / 64;
@@ -1805,6 +1943,7 @@ hipError_t launch_uat978(const UatArgs& a, hipStream_t stream)
 hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, bool ordered, hipStream_t stream)
 {
     if (ncand == 0) return hipSuccess;
+    uint32_t* const work = a.demod_work;
     const uint32_t nranges = ncand >= 4096 ? kUatDemodRanges : 1u;
     // one wave per match up to what the device holds at once (two workgroups per CU, 256 CUs: the waves draw tickets from there on)
     constexpr uint32_t kResidentWaves = 2 * 256 * kUatDemodWaves;
@@ -1814,7 +1953,7 @@ hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, bool ordered, h
     const uint32_t g = (waves + kUatDemodWaves - 1) / kUatDemodWaves;
     if (!ordered && ncand > 1)
     { // (a single look-up needs no reset: one wave, one item, and the loop ends whatever the counter holds; the next ordering pass zeroes it)
-        hipError_t e = hipMemsetAsync(a.demod_work, 0, kUatDemodRanges * 32 * sizeof(uint32_t), stream);
+        hipError_t e = hipMemsetAsync(work, 0, kUatDemodRanges * 32 * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
     }
     const uint32_t* up_list  = ordered ? a.up_list : nullptr;
@@ -1822,11 +1961,11 @@ hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, bool ordered, h
     uint32_t*       chase    = ordered ? a.next_bit : nullptr; // the frames behind a frame are followed for the ordered list only
     if (a.phases_given)
         hipLaunchKernelGGL(uat_demod_kernel<true>, dim3(g), dim3(64 * kUatDemodWaves), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
-                           a.payloads, a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges, up_list, up_count, a.single_word,
+                           a.payloads, a.uplink_payloads, a.uplink_cap, a.counts + 1, work, nranges, up_list, up_count, a.single_word,
                            a.lenbits, chase, a.extras, a.extra_payloads, a.extra_cap, a.counts);
     else
         hipLaunchKernelGGL(uat_demod_kernel<false>, dim3(g), dim3(64 * kUatDemodWaves), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
-                           a.payloads, a.uplink_payloads, a.uplink_cap, a.counts + 1, a.demod_work, nranges, up_list, up_count, a.single_word,
+                           a.payloads, a.uplink_payloads, a.uplink_cap, a.counts + 1, work, nranges, up_list, up_count, a.single_word,
                            a.lenbits, chase, a.extras, a.extra_payloads, a.extra_cap, a.counts);
     return hipGetLastError();
 }
@@ -1847,6 +1986,15 @@ hipError_t launch_uat978_order(const UatArgs& a, uint32_t ncand, uint32_t* scrat
     hipLaunchKernelGGL(uat_order_prefix_kernel, dim3(1), dim3(1024), 0, stream, offset, nspans, a.demod_work, a.counts + 2);
     hipLaunchKernelGGL(uat_order_scatter_kernel, dim3(gc), dim3(256), 0, stream, a.cand, ncand, offset, fill, sorted);
     hipLaunchKernelGGL(uat_order_within_kernel, dim3(gs), dim3(256), 0, stream, offset, fill, nspans, sorted, a.up_list, a.counts + 2);
+    return hipGetLastError();
+}
+
+hipError_t launch_uat978_order_bins(const UatArgs& a, uint32_t ncand, uint32_t* sorted, hipStream_t stream)
+{
+    if (ncand == 0) return hipSuccess; // (nothing was placed: both fill-count arrays are still all zero)
+    const uint32_t nbins = (uint32_t)((a.nsamples + (1u << kUatBinShift) - 1) >> kUatBinShift);
+    hipLaunchKernelGGL(uat_order_bins_kernel, dim3((nbins + kUatBinThreads - 1) / kUatBinThreads), dim3(kUatBinThreads), 0, stream, a.bin_fill, a.bin_fill_next,
+                       a.bins_cap, a.bin_slots, nbins, sorted, a.cand_cap, a.up_list, a.counts + 2, a.demod_work);
     return hipGetLastError();
 }
 

@@ -180,6 +180,15 @@ struct adsb_amd_uat
     Pinned<uint8_t>   pay_h;
     Pinned<uint8_t>   up_h;
     Pinned<uint32_t>  cand_h;
+    // the bins of the match search (uat978.h; round 6): two fill-count arrays that swap roles per call, kUatBinCap slots per bin
+    uint32_t*  bin_fill_d[2] = {nullptr, nullptr};
+    uint32_t*  bin_slots_d = nullptr;
+    uint32_t   bins_cap = 0;
+    int        bin_phase = 0;
+    bool       bins_dirty = false;   // a call ended between the match search and the ordering pass: the current fill counts are not zero
+    bool       bins_ordered = false; // the last call's ordering was the one-launch form
+    hipStream_t copy_stream2 = nullptr; // the frame bytes beside the records: two copy engines share the host link (46 -> ~55 GB/s)
+    hipEvent_t  ev_copy2 = nullptr;
     std::unordered_map<uint64_t, uint32_t> extra; // positions asked for on top of those: (index << 1 | kind) -> record
     uint32_t   nrecords = 0, nmain = 0, nuplink = 0;
     // the loop's decisions, made on the device (uat978.h: UatArgs from next_bit on)
@@ -219,12 +228,14 @@ struct adsb_amd_uat
     {
         stop_pipeline();
         (void)hipSetDevice(device);
-        for (void* p : {(void*)lut_d, (void*)rs_d, (void*)signs_d, (void*)cand_d, (void*)sorted_d, (void*)order_scratch_d, (void*)counts_d, (void*)demod_work_d, (void*)recs_d, (void*)pay_d, (void*)up_d, (void*)in_d,
+        for (void* p : {(void*)lut_d, (void*)rs_d, (void*)signs_d, (void*)cand_d, (void*)sorted_d, (void*)order_scratch_d, (void*)counts_d, (void*)demod_work_d, (void*)bin_fill_d[0], (void*)bin_fill_d[1], (void*)bin_slots_d, (void*)recs_d, (void*)pay_d, (void*)up_d, (void*)in_d,
                         (void*)stage_d, (void*)stage_tmp_d, (void*)next_bit_d, (void*)succ_d, (void*)exit_d, (void*)emit_d, (void*)marks_d, (void*)extras_d, (void*)extra_pay_d})
             if (p) (void)hipFree(p);
         if (counts_h) (void)hipHostFree(counts_h);
         for (auto e : ev)
             if (e) (void)hipEventDestroy(e);
+        if (ev_copy2) (void)hipEventDestroy(ev_copy2);
+        if (copy_stream2) (void)hipStreamDestroy(copy_stream2);
         if (ev_demod) (void)hipEventDestroy(ev_demod);
         if (ev_counts) (void)hipEventDestroy(ev_counts);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -237,6 +248,8 @@ struct adsb_amd_uat
         UAT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         UAT_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         for (auto& e : ev) UAT_HIP(hipEventCreate(&e));
+        UAT_HIP(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
+        UAT_HIP(hipEventCreateWithFlags(&ev_copy2, hipEventDisableTiming));
         UAT_HIP(hipEventCreateWithFlags(&ev_demod, hipEventDisableTiming));
         UAT_HIP(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
         // InitATan2Table, UAT978.cpp:76-100
@@ -276,6 +289,7 @@ struct adsb_amd_uat
             if (v && *v && *v != '0') host_loop_only = true;
         }
         UAT_HIP(hipMalloc(&demod_work_d, kUatDemodRanges * 32 * sizeof(uint32_t)));
+        UAT_HIP(hipMemset(demod_work_d, 0, kUatDemodRanges * 32 * sizeof(uint32_t)));
         UAT_HIP(hipHostMalloc(&counts_h, kUatCountWords * sizeof(uint32_t))); // uat978.h: UatCount
         UAT_HIP(hipMalloc(&stage_d, 65536 * sizeof(uint16_t)));
         UAT_HIP(hipMalloc(&stage_tmp_d, 65536 * sizeof(uint16_t)));
@@ -328,6 +342,22 @@ struct adsb_amd_uat
         cand_cap = want;
         return ADSB_AMD_OK;
     }
+    int reserve_bins(uint64_t nsamples)
+    {
+        const uint32_t want = (uint32_t)((nsamples + (1u << kUatBinShift) - 1) >> kUatBinShift);
+        if (want <= bins_cap) return ADSB_AMD_OK;
+        for (void* q : {(void*)bin_fill_d[0], (void*)bin_fill_d[1], (void*)bin_slots_d})
+            if (q) (void)hipFree(q);
+        bin_fill_d[0] = bin_fill_d[1] = bin_slots_d = nullptr, bins_cap = 0;
+        for (auto& f : bin_fill_d)
+        {
+            UAT_HIP(hipMalloc(&f, (size_t)want * sizeof(uint32_t)));
+            UAT_HIP(hipMemsetAsync(f, 0, (size_t)want * sizeof(uint32_t), stream));
+        }
+        UAT_HIP(hipMalloc(&bin_slots_d, (size_t)want * kUatBinCap * sizeof(uint32_t)));
+        bins_cap = want, bins_dirty = false;
+        return ADSB_AMD_OK;
+    }
     int reserve_uplink(uint32_t want)
     {
         if (want <= up_cap) return ADSB_AMD_OK;
@@ -344,6 +374,7 @@ struct adsb_amd_uat
         a.in = in, a.lut = lut_d, a.rs_tables = rs_d, a.nsamples = n, a.phases_given = phases_given ? 1 : 0;
         a.signs = signs_d, a.cand = cand_d, a.cand_cap = cand_cap, a.counts = counts_d; // demod_on_device points a.cand at sorted_d
         a.recs = recs_d, a.payloads = pay_d, a.uplink_payloads = up_d, a.uplink_cap = up_cap, a.demod_work = demod_work_d;
+        if (!phases_given) a.bin_fill = bin_fill_d[bin_phase], a.bin_fill_next = bin_fill_d[bin_phase ^ 1], a.bins_cap = bins_cap, a.bin_slots = bin_slots_d;
         a.up_list = order_scratch_d ? order_scratch_d + 2 * (size_t)((n + 32767) / 32768) + 2 : nullptr;
         a.lenbits = (int64_t)(n / 2) - (kUatSyncBits + kUatUplinkBits);
         a.next_bit = next_bit_d, a.extras = extras_d, a.extra_payloads = extra_pay_d, a.extra_cap = extra_cap;
@@ -359,7 +390,7 @@ struct adsb_amd_uat
     {
         if (n >= (1ull << 31)) return fail(ADSB_AMD_EINVAL, "UAT stream longer than 2^31 samples per call");
         part_in = nullptr; // any call takes the buffers a scanned, undecided part was waiting in
-        int rc = phases_given ? reserve_signs(n) : ADSB_AMD_OK;
+        int rc = phases_given ? reserve_signs(n) : reserve_bins(n);
         if (!rc) rc = reserve_cand(std::max<uint32_t>(cand_cap, 4096));
         if (rc) return rc;
         nrecords = nmain = nuplink = nextras = 0;
@@ -368,11 +399,18 @@ struct adsb_amd_uat
         const double t0 = now_ms();
         for (int attempt = 0;; attempt++)
         {
+            if (bins_dirty && !phases_given)
+            { // an earlier call (or attempt) filled bins that no ordering pass has taken
+                UAT_HIP(hipMemsetAsync(bin_fill_d[bin_phase], 0, (size_t)bins_cap * sizeof(uint32_t), stream));
+                bins_dirty = false;
+            }
             const UatArgs a = args(in_dev, n, phases_given);
             UAT_HIP(hipEventRecord(ev[0], stream));
+            if (!phases_given) bins_dirty = true;
             UAT_HIP(launch_uat978(a, stream));
             UAT_HIP(hipEventRecord(ev[1], stream));
-            UAT_HIP(hipMemcpyAsync(counts_h, counts_d, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            static_assert(kUatCountMatches == 0 && kUatCountBinOverflow < 8, "one copy of eight words brings both");
+            UAT_HIP(hipMemcpyAsync(counts_h, counts_d, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             UAT_HIP(hipStreamSynchronize(stream));
             const uint32_t ncand = counts_h[0];
             if (ncand + 64 > cand_cap)
@@ -386,6 +424,7 @@ struct adsb_amd_uat
             const double t1 = now_ms();
             rc = reserve_uplink(ncand + 64 + kUatExtraCap); // at most one decoded payload per match and per frame behind one
             if (rc) return rc;
+            bins_ordered = !phases_given && ncand && counts_h[kUatCountBinOverflow] == 0;
             { // stream order on the device, so that the records arrive in the order the scan loop walks them
                 const size_t words = 2 * (size_t)((n + 32767) / 32768) + 2 + cand_cap; // launch_uat978_order: two words per 32 768-sample bin, then the uplink positions
                 if (words > order_scratch_words)
@@ -395,7 +434,12 @@ struct adsb_amd_uat
                     UAT_HIP(hipMalloc(&order_scratch_d, words * sizeof(uint32_t)));
                     order_scratch_words = words;
                 }
-                UAT_HIP(launch_uat978_order(args(in_dev, n, phases_given), ncand, order_scratch_d, sorted_d, stream));
+                if (bins_ordered)
+                { // one launch: the match search left the matches binned by position (round 6); the pass zeroes the other fill-count array, the next call's
+                    UAT_HIP(launch_uat978_order_bins(args(in_dev, n, phases_given), ncand, sorted_d, stream));
+                    bins_dirty = false, bin_phase ^= 1;
+                }
+                else UAT_HIP(launch_uat978_order(args(in_dev, n, phases_given), ncand, order_scratch_d, sorted_d, stream)); // phases as input (small), or a bin that ran over
             }
             rc = launch_demod(in_dev, n, phases_given, ncand);
             if (!rc && !hold_decisions) rc = decide_and_fetch(in_dev, n, phases_given, ncand);
@@ -418,6 +462,9 @@ struct adsb_amd_uat
         UAT_HIP(recs_h.reserve(count, 0));
         UAT_HIP(pay_h.reserve((size_t)count * kUatPayloadStride, 0));
         UAT_HIP(hipEventRecord(ev[2], stream));
+        // (Round 6 measured the pass cut into four launches over consecutive parts of the list, a part's records on their way to the host beside the
+        // next part: 4 x 84 us instead of 197 -- a wave works through thirteen matches of a launch, an uplink match takes ten times an ADS-B one, and a
+        // quarter of the list per launch leaves the waves nothing to even that out with.  One launch.)
         UAT_HIP(launch_uat978_demod(d, count, true, stream));
         UAT_HIP(hipEventRecord(ev[3], stream));
         UAT_HIP(hipEventRecord(ev_demod, stream));
@@ -440,7 +487,7 @@ struct adsb_amd_uat
             {
                 UAT_HIP(marks_h.reserve(mark_words, 0));
                 UAT_HIP(hipEventRecord(ev[5], stream));
-                UAT_HIP(launch_uat978_decide(a, count, sorted_d, stream));
+                UAT_HIP(launch_uat978_decide(a, count, sorted_d, stream, false));
                 UAT_HIP(hipEventRecord(ev[4], stream));
                 UAT_HIP(hipMemcpyAsync(marks_h.p, marks_d, mark_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 UAT_HIP(hipMemcpyAsync(extras_h.p, extras_d, kExtraFirstCopy * sizeof(uat_extra_t), hipMemcpyDeviceToHost, stream));
@@ -485,7 +532,9 @@ struct adsb_amd_uat
             UAT_HIP(hipMemcpyAsync(counts_h + kUatCountUplinkSlots, counts_d + kUatCountUplinkSlots, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, copy_stream));
             UAT_HIP(hipEventRecord(ev_counts, copy_stream));
             UAT_HIP(hipMemcpyAsync(recs_h.p, recs_d, (size_t)count * sizeof(uat_rec_t), hipMemcpyDeviceToHost, copy_stream));
-            UAT_HIP(hipMemcpyAsync(pay_h.p, pay_d, (size_t)count * kUatPayloadStride, hipMemcpyDeviceToHost, copy_stream));
+            UAT_HIP(hipStreamWaitEvent(copy_stream2, ev_demod, 0)); // (round 6) the frame bytes on a second copy stream, beside the records
+            UAT_HIP(hipMemcpyAsync(pay_h.p, pay_d, (size_t)count * kUatPayloadStride, hipMemcpyDeviceToHost, copy_stream2));
+            UAT_HIP(hipEventRecord(ev_copy2, copy_stream2));
             if (decide)
             {
                 UAT_HIP(hipMemcpyAsync(extras_h.p, extras_d, kExtraFirstCopy * sizeof(uat_extra_t), hipMemcpyDeviceToHost, copy_stream));
@@ -493,7 +542,7 @@ struct adsb_amd_uat
                 // (2) the decisions, on the call's own stream, beside those copies
                 UAT_HIP(marks_h.reserve(mark_words, 0));
                 UAT_HIP(hipEventRecord(ev[5], stream));
-                UAT_HIP(launch_uat978_decide(a, count, sorted_d, stream));
+                UAT_HIP(launch_uat978_decide(a, count, sorted_d, stream, true)); // (1024 threads wide: the chip is this call's)
                 UAT_HIP(hipEventRecord(ev[4], stream));
                 UAT_HIP(hipMemcpyAsync(marks_h.p, marks_d, mark_words * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 UAT_HIP(hipMemcpyAsync(counts_h + kUatCountFinalBit, counts_d + kUatCountFinalBit, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -502,7 +551,13 @@ struct adsb_amd_uat
             UAT_HIP(hipEventSynchronize(ev_counts));
             const uint32_t up_total = counts_h[kUatCountUplinkSlots];
             const bool     overflow = counts_h[kUatCountOverflow] != 0;
-            if (up_total > up_cap && !overflow) return fail(ADSB_AMD_EHIP, "UAT uplink payload area too small");
+            if (up_total > up_cap && !overflow)
+            { // copies and kernels of this call are still on their way into arrays the next call may replace: both streams drained first
+                (void)hipStreamSynchronize(copy_stream);
+                (void)hipStreamSynchronize(copy_stream2);
+                (void)hipStreamSynchronize(stream);
+                return fail(ADSB_AMD_EHIP, "UAT uplink payload area too small");
+            }
             const uint32_t up_have = std::min(up_total, up_cap);
             nextras                = std::min<uint32_t>(counts_h[kUatCountExtras], extra_cap);
             decided                = decide && !overflow;
@@ -524,6 +579,7 @@ struct adsb_amd_uat
                                        (size_t)(nextras - kExtraFirstCopy) * kUatPayloadStride, hipMemcpyDeviceToHost, copy_stream));
             }
             UAT_HIP(hipStreamSynchronize(copy_stream));
+            UAT_HIP(hipEventSynchronize(ev_copy2));
             UAT_HIP(hipStreamSynchronize(stream));
         }
         nrecords = count;
