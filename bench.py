@@ -225,7 +225,15 @@ def main():
                 out["uat978"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     else:
-        out = bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch)
+        try:
+            out = bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch)
+        except BaseException as e:
+            # a rank that fails leaves ONE JSON line of its own behind (every rank that fails does; rank 0's is not special here): what failed, and
+            # which record transport each rank had ended on as far as this rank knows
+            print(json.dumps({"metric": "Msamples/s demodulated (1090ES u8 IQ -> Mode S frame records)", "value": None, "n_gpus": world, "failed_rank": rank,
+                              "error": repr(e)[:400], "record_transport_by_rank": getattr(args, "transport_by_rank", None),
+                              "record_transport_this_rank": None if getattr(args, "transport_by_rank", None) is None else args.transport_by_rank[rank]}), flush=True)
+            raise
         if rank == 0:
             print(json.dumps(out), flush=True)
     if dist is not None:
@@ -267,13 +275,26 @@ def make_runner(args, sc, d_iq, BB, stream):
                 rec = took(sc.fetch_packed(0, copy=False))
                 note(0)
             return rec, acc[0], acc[1], acc[2]
+        if not sc.has_split_fetch():  # (an older build under ADSB_AMD_LIB: tools/ab.py)
+            sc.submit(ptr(), nbytes, BB, stream, 0)
+            for i in range(1, steps):
+                sc.submit(ptr(), nbytes, BB, stream, i & 1)
+                rec = took(sc.fetch_packed((i - 1) & 1, copy=False))
+                note((i - 1) & 1)
+            rec = took(sc.fetch_packed((steps - 1) & 1, copy=False))
+            note((steps - 1) & 1)
+            return rec, acc[0], acc[1], acc[2]
+        # Two scans on the stream at any time.  A step's records: wait for its count (its ordering pass rides in front of the scan kernel after it),
+        # start the copy, submit the slot's NEXT scan beside the copy (a scan writes the slot's raw regions only), then wait for the copy.
         sc.submit(ptr(), nbytes, BB, stream, 0)
-        for i in range(1, steps):
-            sc.submit(ptr(), nbytes, BB, stream, i & 1)
-            rec = took(sc.fetch_packed((i - 1) & 1, copy=False))
-            note((i - 1) & 1)
-        rec = took(sc.fetch_packed((steps - 1) & 1, copy=False))
-        note((steps - 1) & 1)
+        if steps > 1:
+            sc.submit(ptr(), nbytes, BB, stream, 1)
+        for i in range(steps):
+            sc.fetch_packed_begin(i & 1)
+            note(i & 1)
+            if i + 2 < steps:
+                sc.submit(ptr(), nbytes, BB, stream, i & 1)
+            rec = took(sc.fetch_packed_end(i & 1, copy=False))
         return rec, acc[0], acc[1], acc[2]
     run.delivered = made
     return run
@@ -620,6 +641,12 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
                 print("bench: node-shared record segments unavailable (%s), gathering the records over RCCL" % e, file=sys.stderr)
     rg = RootGather(cap, dtype=A.PACKED_DTYPE)
     step_no = [0]
+    # which transport every rank ended on (they fall back together by construction; the line shows it rank by rank, and so does the line a
+    # failed job leaves: main())
+    mine = "NodeGather" if ng is not None else "RootGather"
+    by_rank = [None] * world
+    dist.all_gather_object(by_rank, mine)
+    args.transport_by_rank = by_rank
 
     def deliver_rccl(slot):
         """Records of `slot` -> rank 0 (collective).  Device path: scanner -> send buffer (device to device, on the side stream) ->
@@ -647,8 +674,9 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
             with torch.cuda.stream(comm):
                 n = sc.fetch_device(slot, ng.records_ptr(step), cap, comm.cuda_stream, packed=True)
                 ev = comm.record_event()
-                # (No compute.wait_event(ev): the next scan of this slot is submitted only after ng.flush() has waited for this event on
-                # the host -- run() below --, which is when the header is written too.  The wait on the stream cost every scan a packet.)
+                # (No compute.wait_event(ev): the dense array this copy reads is next written by the ordering pass in front of the scan kernel
+                # two submits on, and that submit comes after ng.flush() has waited for this event on the host -- run() below --, which is
+                # when the header is written too.  The wait on the stream cost every scan a packet.)
                 return ng.gather(step, n, first, wait=False, event=ev)
         rec = sc.fetch_packed(slot, copy=False)
         ng.host_records_view(step)[:len(rec)] = rec
@@ -687,9 +715,13 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
         wd.phase("submit", 0)
         sc.submit(d_iq.data_ptr(), nbytes, BB, compute.cuda_stream, 0)
         for i in range(1, steps):
-            if ng is not None:
-                ng.flush()  # the copy of this slot's last records (step i - 2) is done: its header goes out, the slot may be scanned into again
+            # (Round 6: the slot is scanned into again while the copy of its last records, step i - 2, may still be on its way -- a scan writes the
+            # slot's raw regions only; the dense array the copy reads is written by the ordering pass of THIS scan, in front of the scan kernel of
+            # step i + 1, which is submitted after the flush of the next trip.  The count of step i - 1 reaches the host some tens of microseconds into
+            # the kernel submitted here, so waiting for that copy first, as until round 5, would leave the GPU without a kernel.)
             sc.submit(d_iq.data_ptr(), nbytes, BB, compute.cuda_stream, i & 1)
+            if ng is not None:
+                ng.flush()  # the copy of step i - 2 is done (or is waited for): its header goes out
             settle(prev, resolver)  # rank 0 takes (and releases) the step before, whose hand-over ran beside a scan
             prev = deliver((i - 1) & 1)
             k_ms += sc.timing((i - 1) & 1)[0]
@@ -826,6 +858,7 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
                                   "all": [round(x, 4) for x in per_rank]},
             "independent_shards_value": round(samples_all * args.steps / indep / 1e6, 1),
             "record_transports_agree": transports_agree,
+            "record_transport_by_rank": by_rank,
             "sharded_over_plain": sharded_over_plain,
             "gather_bytes_per_step": int(nrec * 32),
         }
@@ -1007,29 +1040,8 @@ def bench_uat978_one_stream(args, rank, local_rank, world, dist, A, synth, torch
     word = torch.zeros(1, dtype=torch.int64, device="cuda" if on_device else "cpu")
 
     def step(collect=False):
-        wd.phase("part scan")
-        u.part_scan(buf.data_ptr(), w1 - w0)
-        at = 0
-        if rank > 0:
-            wd.phase("waiting for the rank before")
-            dist.recv(word, src=rank - 1)
-            at = int(word.item())
-            if at < 0:  # a rank before this one failed: pass the word on and stop at once (nobody sits in recv until a watchdog fires)
-                if rank < world - 1:
-                    dist.send(word, dst=rank + 1)
-                raise RuntimeError("rank %d: the part of an earlier rank failed" % rank)
-        wd.phase("part finish")
-        try:
-            frames, exit_local, done = u.part_finish(b - w0, e - w0, max(at - w0 // 2, 0), last, offset=w0, collect=collect)
-        except Exception:
-            if rank < world - 1:
-                word[0] = -1
-                dist.send(word, dst=rank + 1)
-            raise
-        if rank < world - 1:
-            word[0] = exit_local + w0 // 2
-            dist.send(word, dst=rank + 1)
-        return frames, done + w0
+        frames, consumed, _ = shard.uat_chain_step(u, dist, word, rank, world, (w0, w1, b, e, last), buf.data_ptr(), collect=collect, phase=wd.phase)
+        return frames, consumed
 
     def barrier():
         wd.phase("barrier")

@@ -182,6 +182,11 @@ int adsb_amd_scan_1090_fetch_decoded(adsb_amd_ctx_t* ctx, int slot, const adsb_a
 int adsb_amd_set_outputs(adsb_amd_ctx_t* ctx, unsigned mask);
 /* fetch of the packed form (needs ADSB_AMD_OUT_PACKED): same order, count and lifetime as the records. */
 int adsb_amd_scan_1090_fetch_packed(adsb_amd_ctx_t* ctx, int slot, const adsb_amd_packed_t** packed, size_t* n);
+/* The same fetch in two halves, for a loop that keeps the GPU fed: _begin waits for the slot's count (*n), starts the copy of the packed records and
+ * leaves the slot free for its next adsb_amd_scan_1090_submit; _end waits for that copy and returns the pointer (valid until the slot's next _begin or
+ * fetch).  Every _begin has to be followed by its _end before the slot is fetched again. */
+int adsb_amd_scan_1090_fetch_packed_begin(adsb_amd_ctx_t* ctx, int slot, size_t* n);
+int adsb_amd_scan_1090_fetch_packed_end(adsb_amd_ctx_t* ctx, int slot, const adsb_amd_packed_t** packed, size_t* n);
 /* The same wait, but the sorted records are copied into `dst_device` (room for `cap` records: memory of the same GPU, or page-locked /
  * HIP-registered host memory) on `hip_stream` (NULL: an internal stream, and the call returns after the copy has completed): for the
  * hand-over of the sharded recorded-file case -- an RCCL gather of the records from device buffers, or every

@@ -34,7 +34,7 @@ ON_CHANGED = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
 
 EXPORTS = [
     "adsb_amd_version", "adsb_amd_create", "adsb_amd_create_mode", "adsb_amd_handler_create_mode", "adsb_amd_resolver_set_mode", "adsb_amd_destroy", "adsb_amd_last_error", "adsb_amd_scan_1090",
-    "adsb_amd_scan_1090_submit", "adsb_amd_scan_1090_fetch", "adsb_amd_scan_1090_fetch_decoded", "adsb_amd_scan_1090_fetch_packed", "adsb_amd_set_outputs", "adsb_amd_resolver_feed_packed", "adsb_amd_handler_set_frames", "adsb_amd_scan_1090_fetch_device", "adsb_amd_scan_1090_fetch_device_packed", "adsb_amd_scan_1090_timing", "adsb_amd_set_timing", "adsb_amd_magnitude_1090",
+    "adsb_amd_scan_1090_submit", "adsb_amd_scan_1090_fetch", "adsb_amd_scan_1090_fetch_decoded", "adsb_amd_scan_1090_fetch_packed", "adsb_amd_scan_1090_fetch_packed_begin", "adsb_amd_scan_1090_fetch_packed_end", "adsb_amd_set_outputs", "adsb_amd_resolver_feed_packed", "adsb_amd_handler_set_frames", "adsb_amd_scan_1090_fetch_device", "adsb_amd_scan_1090_fetch_device_packed", "adsb_amd_scan_1090_timing", "adsb_amd_set_timing", "adsb_amd_magnitude_1090",
     "adsb_amd_decode_1090", "adsb_amd_decode_record_host", "adsb_amd_resolver_feed_decoded", "adsb_amd_cpr_nl", "adsb_amd_cpr_global", "adsb_amd_cpr_global_batch",
     "adsb_amd_resolver_create", "adsb_amd_resolver_destroy", "adsb_amd_resolver_set_sample_clock", "adsb_amd_resolver_feed",
     "adsb_amd_resolver_aircraft_count", "adsb_amd_count_callback", "adsb_amd_handler_create", "adsb_amd_handler_destroy", "adsb_amd_handler_last_error",
@@ -84,6 +84,9 @@ def lib():
         if hasattr(L, "adsb_amd_set_outputs"):  # absent from the older builds tools/ab.py compares against
             L.adsb_amd_set_outputs.argtypes = [C.c_void_p, C.c_uint]
             L.adsb_amd_scan_1090_fetch_packed.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+            if hasattr(L, "adsb_amd_scan_1090_fetch_packed_begin"):  # absent from the older builds tools/ab.py compares against (the export test covers the product)
+                L.adsb_amd_scan_1090_fetch_packed_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+                L.adsb_amd_scan_1090_fetch_packed_end.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
             L.adsb_amd_resolver_feed_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
             L.adsb_amd_resolver_feed_packed.restype = C.c_long
             L.adsb_amd_handler_set_frames.argtypes = [C.c_void_p, C.c_int]
@@ -251,6 +254,24 @@ class Scanner:
         """The packed hand-over form (record head + decoded fields, 32 bytes, no message bytes); needs set_outputs(OUT_PACKED)."""
         p, n = C.c_void_p(), C.c_size_t()
         self._check(self._l.adsb_amd_scan_1090_fetch_packed(self._h, slot, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, PACKED_DTYPE)
+        arr = np.frombuffer((C.c_uint8 * (n.value * 32)).from_address(p.value), dtype=PACKED_DTYPE)
+        return arr.copy() if copy else arr
+
+    def has_split_fetch(self):
+        return hasattr(self._l, "adsb_amd_scan_1090_fetch_packed_begin")
+
+    def fetch_packed_begin(self, slot=0):
+        """First half of fetch_packed: waits for the slot's count, starts the copy and frees the slot for its next submit.  Returns the count."""
+        n = C.c_size_t()
+        self._check(self._l.adsb_amd_scan_1090_fetch_packed_begin(self._h, slot, C.byref(n)))
+        return n.value
+
+    def fetch_packed_end(self, slot=0, copy=True):
+        """Second half: waits for the copy begun by fetch_packed_begin(slot)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._l.adsb_amd_scan_1090_fetch_packed_end(self._h, slot, C.byref(p), C.byref(n)))
         if n.value == 0:
             return np.zeros(0, PACKED_DTYPE)
         arr = np.frombuffer((C.c_uint8 * (n.value * 32)).from_address(p.value), dtype=PACKED_DTYPE)

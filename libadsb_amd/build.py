@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libadsb_amd.so")
 SYNTH = os.path.join(HERE, "libadsb_synth.so")
 
 HIP_SOURCES = ["scan1090.hip", "scan2400.hip", "uat978.hip", "capi.cpp", "resolver1090.cpp", "transport.cpp", "adsb1090_gpu_handler.cpp", "uat978_host.cpp", "uat978_gpu_handler.cpp"]
-HIP_DEPS = HIP_SOURCES + ["scan1090.h", "uat978.h", "rs978.h", "resolver1090.hpp", "decode1090.h", "transport.hpp", "scan_common.hip.h", "diag.hip.h", os.path.join(ROOT, "include", "adsb_amd.h"),
+HIP_DEPS = HIP_SOURCES + ["scan1090.h", "uat978.h", "rs978.h", "resolver1090.hpp", "decode1090.h", "transport.hpp", "scan_common.hip.h", "gather1090.hip.h", "diag.hip.h", os.path.join(ROOT, "include", "adsb_amd.h"),
                            os.path.join(ROOT, "include", "libadsb_iface.hpp")]
 
 

@@ -61,6 +61,12 @@ struct Slot
     hipEvent_t         ev_scan0 = nullptr, ev_scan1 = nullptr, ev_order = nullptr;
     uint32_t           seq = 0;            // launches of this slot: the stamp the ordering pass writes beside the count
     bool               pending = false, timed = false;
+    // Round 6: the slot's ordering pass is not launched with its scan.  The NEXT scan kernel on the same stream (the other slot's) does it in front of
+    // its own work (gather1090.hip.h) -- `gather_attached` --, or, when the slot is waited for before any such kernel came, a launch of its own does.
+    bool               gather_launched = false, gather_attached = false;
+    bool               copying = false;  // adsb_amd_scan_1090_fetch_packed_begin has put the slot's records on the copy stream; _end has not been called
+    size_t             copy_n  = 0;      // their number
+    uint32_t*          next_sums = nullptr; // the sum array this scan's ordering pass zeroes (the slot's other one)
     bool               events = false;     // this scan has the two timing events around its kernel
     // the submitted job (needed again when a chunk region overflows and the scan is repeated with a larger cap)
     ScanArgs    args{};
@@ -143,7 +149,7 @@ int ensure_slot(adsb_amd_ctx* c, Slot& s, size_t chunks, size_t cap, unsigned ma
     free_slot(s);
     size_t nch = chunks ? chunks : 1;
     HIP_TRY(c, hipMalloc(&s.counts, nch * sizeof(uint32_t)));
-    s.sums_words = ((nch + kOrderChunks - 1) / kOrderChunks) * kSumStride;
+    s.sums_words = sums_entries(nch) * kSumStride;
     s.sums_phase = 0;
     HIP_TRY(c, hipMalloc(&s.block_sums, 2 * s.sums_words * sizeof(uint32_t)));
     HIP_TRY(c, hipMemset(s.block_sums, 0, 2 * s.sums_words * sizeof(uint32_t)));
@@ -214,6 +220,22 @@ int make_args(adsb_amd_ctx* c, const void* iq_device, size_t nbytes, size_t buff
     return ADSB_AMD_OK;
 }
 
+// what the ordering pass of the slot's current scan needs (scan1090.h)
+GatherArgs gather_args(const Slot& s)
+{
+    GatherArgs g;
+    g.chunk_records = s.args.chunk_records, g.chunk_dir = s.args.chunk_dir, g.block_sums = s.args.block_sums;
+    g.nchunks = s.args.total_chunks, g.nblocks = (s.args.total_chunks + kOrderChunks - 1u) / kOrderChunks;
+    g.cap = s.args.cap, g.chunks_per_buf = s.args.chunks_per_buf ? s.args.chunks_per_buf : 1u;
+    g.dense   = (s.produced & ADSB_AMD_OUT_RECORDS) ? s.dense : nullptr;
+    g.decoded = (s.produced & ADSB_AMD_OUT_DECODED) ? s.decoded : nullptr;
+    g.packed  = (s.produced & ADSB_AMD_OUT_PACKED) ? s.packed : nullptr;
+    g.state   = s.total_d;
+    g.next_block_sums = s.next_sums, g.next_entries = (uint32_t)(s.sums_words / kSumStride), g.work_counters = s.work_d;
+    g.host_word = s.total_h_dev, g.stamp = s.seq, g.stamps = s.args.stamps;
+    return g;
+}
+
 int enqueue(adsb_amd_ctx* c, Slot& s)
 {
     s.args.chunk_records = s.regions;
@@ -230,20 +252,35 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     // have kept it off a CU removed: the pass rewritten without LDS (a scan's sixteen waves hold all of a CU's) and held to 64 VGPRs
     // (the scan's waves leave that many per SIMD) -- 0.263 -> 0.313 and 0.280 -> 0.333 ms per step.)
     s.args.stamps = c->stamps_d ? c->stamps_d + (size_t)4 * kStampGroups * (c->stamp_no++ % kStampSteps) : nullptr;
+    s.next_sums   = next_sums;
     s.seq++;
     s.events = c->timing_every != 0 && (c->submits++ % c->timing_every) == 0;
     // the two timing events ride on the kernel's dispatch (scan1090.h); an empty input launches nothing and is not timed
     s.events = s.events && s.args.total_chunks != 0;
-    if (c->mode == ADSB_AMD_MODE_2400) HIP_TRY(c, launch_scan2400(s.args, s.total_d, s.stream, s.events ? s.ev_scan0 : nullptr, s.events ? s.ev_scan1 : nullptr));
-    else HIP_TRY(c, launch_scan1090(s.args, s.total_d, s.stream, s.events ? s.ev_scan0 : nullptr, s.events ? s.ev_scan1 : nullptr));
-    HIP_TRY(c, launch_order1090(s.args, (s.produced & ADSB_AMD_OUT_RECORDS) ? s.dense : nullptr, (s.produced & ADSB_AMD_OUT_DECODED) ? s.decoded : nullptr,
-                                (s.produced & ADSB_AMD_OUT_PACKED) ? s.packed : nullptr, next_sums, (uint32_t)(s.sums_words / kSumStride), s.total_d, s.stream, s.args.total_chunks ? s.ev_order : nullptr,
-                                s.total_h_dev, s.seq));
+    // The other slot's scan, if it is still waiting for its ordering pass on this very stream: this kernel's waves do that first (round 6).
+    Slot&             o      = c->slot[&s == &c->slot[0] ? 1 : 0];
+    const bool        attach = o.pending && !o.gather_launched && o.stream == s.stream && o.args.total_chunks != 0 && s.args.total_chunks != 0;
+    const GatherArgs  ga     = attach ? gather_args(o) : GatherArgs{};
+    const GatherArgs* gp     = attach ? &ga : nullptr;
+    if (c->mode == ADSB_AMD_MODE_2400) HIP_TRY(c, launch_scan2400(s.args, s.total_d, s.stream, s.events ? s.ev_scan0 : nullptr, s.events ? s.ev_scan1 : nullptr, gp));
+    else HIP_TRY(c, launch_scan1090(s.args, s.total_d, s.stream, s.events ? s.ev_scan0 : nullptr, s.events ? s.ev_scan1 : nullptr, gp));
+    if (attach) o.gather_launched = o.gather_attached = true;
+    s.gather_launched = s.gather_attached = false;
     if (!s.args.total_chunks)
-    { // nothing was launched: no records (otherwise the ordering pass's dispatch carries the event and its last workgroup stores the word)
+    { // nothing was launched: no records, no pass
         HIP_TRY(c, hipEventRecord(s.ev_order, s.stream));
         __atomic_store_n(s.total_h, (unsigned long long)(s.seq & 0x7FFFFFFFu) << 33, __ATOMIC_RELEASE);
+        s.gather_launched = true;
     }
+    return ADSB_AMD_OK;
+}
+
+// the slot's ordering pass as a launch of its own, unless a scan kernel has taken it on (enqueue) or it has been launched already
+int ensure_gather(adsb_amd_ctx* c, Slot& s)
+{
+    if (s.gather_launched) return ADSB_AMD_OK;
+    HIP_TRY(c, launch_gather1090(gather_args(s), s.stream, s.ev_order));
+    s.gather_launched = true, s.gather_attached = false;
     return ADSB_AMD_OK;
 }
 } // namespace
@@ -328,8 +365,8 @@ extern "C" int adsb_amd_create_mode(adsb_amd_ctx_t** out, int device, int mode)
     if ((e = hipMemcpy(c->crc_tab, tab, sizeof(tab), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(crc)", e);
     for (Slot& s : c->slot)
     {
-        if ((e = hipMalloc(&s.total_d, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(total)", e);
-        if ((e = hipMemset(s.total_d, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(total)", e);
+        if ((e = hipMalloc(&s.total_d, kStateWords * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(total)", e);
+        if ((e = hipMemset(s.total_d, 0, kStateWords * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(total)", e);
         if ((e = hipMalloc(&s.work_d, kWorkCounters * kCounterStride * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(work)", e);
         if ((e = hipMemset(s.work_d, 0, kWorkCounters * kCounterStride * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset(work)", e);
         if ((e = hipHostMalloc(&s.total_h, sizeof(unsigned long long), hipHostMallocMapped)) != hipSuccess) return bail("hipHostMalloc(total)", e);
@@ -448,6 +485,10 @@ int wait_count(adsb_amd_ctx* c, Slot& s)
 {
     // Poll the stamp.  The word is written once per launch, by one store; the pass's event is asked now and then so that a launch that
     // failed (the event completes in error, or completes without the word ever arriving) ends the wait instead of hanging it.
+    {
+        const int rc = ensure_gather(c, s);
+        if (rc) return rc;
+    }
     const unsigned long long want = s.seq & 0x7FFFFFFFu;
     for (unsigned spins = 0;; spins++)
     {
@@ -460,7 +501,8 @@ int wait_count(adsb_amd_ctx* c, Slot& s)
         }
         if ((spins & 0x3FFu) == 0x3FFu)
         {
-            const hipError_t q = hipEventQuery(s.ev_order);
+            // (a pass that rides in the other slot's scan kernel has no event of its own: the stream it is on is asked instead)
+            const hipError_t q = s.gather_attached ? hipStreamQuery(s.stream) : hipEventQuery(s.ev_order);
             if (q == hipSuccess)
             { // the pass is done: its store has left the device; give it a moment to land, then it is an error
                 for (int k = 0; k < 1000000; k++)
@@ -495,8 +537,8 @@ int wait_scan(adsb_amd_ctx* c, Slot& s)
             if (rc) return rc;
         }
         if (!s.overflow) break;
-        // the pass that reported the overflow is still zeroing the other sum array and the work counters: it has to be done before the repeat
-        HIP_TRY(c, hipEventSynchronize(s.ev_order));
+        // (the count comes from the pass's last finisher: the other sum array and the work counters have been zeroed, nothing of the pass is still running)
+        if (!s.gather_attached) HIP_TRY(c, hipEventSynchronize(s.ev_order));
         size_t cap = s.cap_per_chunk * 8;
         if (cap > (size_t)2 * kChunk) cap = (size_t)2 * kChunk;
         if (cap == s.cap_per_chunk) return fail(c, ADSB_AMD_EHIP, "record overflow at the maximum region size (internal error)");
@@ -524,8 +566,9 @@ int wait_scan(adsb_amd_ctx* c, Slot& s)
 // enqueues).  A scan without the two events, or events the runtime cannot read, leave the slot untimed.
 void read_timing(Slot& s)
 {
-    s.timed = s.events && hipEventElapsedTime(&s.scan_ms, s.ev_scan0, s.ev_scan1) == hipSuccess &&
-              hipEventElapsedTime(&s.total_ms, s.ev_scan0, s.ev_order) == hipSuccess;
+    s.timed = s.events && hipEventElapsedTime(&s.scan_ms, s.ev_scan0, s.ev_scan1) == hipSuccess;
+    if (s.timed && s.gather_attached) s.total_ms = s.scan_ms; // (the pass was part of a later kernel: no event marks its end)
+    else s.timed = s.timed && hipEventElapsedTime(&s.total_ms, s.ev_scan0, s.ev_order) == hipSuccess;
 }
 
 // Body of fetch; the caller clears `pending` whatever the outcome, so a failed sync or copy never wedges the slot.  `what`: ADSB_AMD_OUT_* to
@@ -540,12 +583,12 @@ int fetch_slot(adsb_amd_ctx* c, Slot& s, unsigned what)
     }
     int rc = ensure_host(c, s, s.nrecords);
     if (rc) return rc;
-    // The count comes from the pass's LAST workgroup: others may still be moving records, zeroing the slot's other sum array or its work
-    // counters.  So the host waits for the pass's event before anything else happens to the slot -- the copy below, or (no records) the
-    // slot's next submit, which may come on another stream.  The stamp is normally there only just before the pass ends: microseconds.
-    // (A stream-side wait instead -- hipStreamWaitEvent on the copy stream -- was not reliable with an event that rides on a dispatch
-    // and is re-used every launch: stale records were seen with three slots in flight.)
-    HIP_TRY(c, hipEventSynchronize(s.ev_order));
+    // Round 6: the count is stored by the pass's LAST FINISHER -- an atomic ticket over its blocks -- after every wave of the pass has had its
+    // stores acknowledged, and the records are written through to memory (gather1090.hip.h): seeing the stamp means the records can be copied and the
+    // slot resubmitted.  (Round 5 stored it from the last workgroup by index and had to wait for the pass's event on top; a stream-side wait on that
+    // re-used, dispatch-riding event had let stale records through.)  A pass launched on its own still has its event waited for: it is there, and
+    // the slot's timing reads it.
+    if (!s.gather_attached) HIP_TRY(c, hipEventSynchronize(s.ev_order));
     if (s.nrecords)
     {
         if (what & ADSB_AMD_OUT_RECORDS)
@@ -589,6 +632,50 @@ extern "C" int adsb_amd_scan_1090_fetch_packed(adsb_amd_ctx_t* c, int slot, cons
     if (rc) return rc;
     if (packed) *packed = s.host_packed;
     if (n) *n = s.nrecords;
+    return ADSB_AMD_OK;
+}
+
+/* The packed fetch in two halves (round 6).  _begin waits for the slot's scan and its ordering pass, puts the copy of the packed records on the copy
+ * stream and returns with the slot free for its next submit: a scan only writes the slot's raw record regions, the dense arrays the copy reads are
+ * written by the ordering pass of THAT scan, which runs in front of the scan kernel after it or in adsb_amd_scan_1090_fetch* -- after _end in a loop
+ * that ends what it begins.  _end waits for the copy.  Between the two the caller submits the slot's next scan: since the ordering pass of a scan
+ * rides in front of the NEXT scan kernel on its stream, its count reaches the host some tens of microseconds into that kernel, and a loop that had to
+ * wait for the 0.16 ms copy before it could submit again would leave the GPU waiting for it. */
+extern "C" int adsb_amd_scan_1090_fetch_packed_begin(adsb_amd_ctx_t* c, int slot, size_t* n)
+{
+    if (!c) return ADSB_AMD_EINVAL;
+    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    Slot& s = c->slot[slot];
+    if (!s.pending) return fail(c, ADSB_AMD_ESTATE, "fetch without submit");
+    if (s.copying) return fail(c, ADSB_AMD_ESTATE, "the slot's last fetch has been begun and not ended");
+    auto body = [&]() -> int {
+        HIP_TRY(c, hipSetDevice(c->device));
+        if (!(s.produced & ADSB_AMD_OUT_PACKED)) return fail(c, ADSB_AMD_ESTATE, "this slot's scan did not produce the packed form (adsb_amd_set_outputs before the submit)");
+        int rc = wait_scan(c, s);
+        if (rc) return rc;
+        if ((rc = ensure_host(c, s, s.nrecords))) return rc;
+        if (!s.gather_attached) HIP_TRY(c, hipEventSynchronize(s.ev_order)); // (see fetch_slot)
+        if (s.nrecords) HIP_TRY(c, hipMemcpyAsync(s.host_packed, s.packed, s.nrecords * sizeof(adsb_amd_packed_t), hipMemcpyDeviceToHost, c->copy_stream));
+        read_timing(s);
+        s.copy_n = s.nrecords, s.copying = true;
+        return ADSB_AMD_OK;
+    };
+    const int rc = body();
+    s.pending    = false;
+    if (rc == ADSB_AMD_OK && n) *n = s.copy_n;
+    return rc;
+}
+extern "C" int adsb_amd_scan_1090_fetch_packed_end(adsb_amd_ctx_t* c, int slot, const adsb_amd_packed_t** packed, size_t* n)
+{
+    if (!c) return ADSB_AMD_EINVAL;
+    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    Slot& s = c->slot[slot];
+    if (!s.copying) return fail(c, ADSB_AMD_ESTATE, "no fetch begun on this slot");
+    s.copying = false;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    if (packed) *packed = s.host_packed;
+    if (n) *n = s.copy_n;
     return ADSB_AMD_OK;
 }
 
@@ -658,7 +745,7 @@ int fetch_device_impl(adsb_amd_ctx_t* c, int slot, void* dst_device, size_t cap,
         if (!(s.produced & (packed ? ADSB_AMD_OUT_PACKED : ADSB_AMD_OUT_RECORDS)))
             return fail(c, ADSB_AMD_ESTATE, "this slot's scan did not produce the array asked for (adsb_amd_set_outputs)");
         if (s.nrecords > cap) return fail(c, ADSB_AMD_ENOSPC, "destination too small");
-        HIP_TRY(c, hipEventSynchronize(s.ev_order)); // (see fetch_slot: always, records or not)
+        if (!s.gather_attached) HIP_TRY(c, hipEventSynchronize(s.ev_order)); // (see fetch_slot)
         if (s.nrecords)
         {
             hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->copy_stream;

@@ -59,8 +59,11 @@ struct ScanArgs
     uint32_t*          block_sums;    // one padded entry (kSumStride words) per kOrderChunks chunks, zero when the scan starts: [0] += records of a
                                       // finished chunk (clamped to cap), [1] |= 1 when a chunk found more than cap
 };
-constexpr uint32_t kOrderChunks = 256; // chunks per entry of block_sums = per workgroup of the ordering pass
+constexpr uint32_t kOrderChunks = 256; // chunks per entry of block_sums = per block of the ordering pass
 constexpr uint32_t kSumStride   = 32; // words between entries: an entry per 128-byte line (one atomic per chunk lands on it)
+inline size_t sums_entries(size_t chunks) { return (chunks + kOrderChunks - 1) / kOrderChunks; } // entries of one sum array for `chunks` chunks
+// a slot's ordering state (GatherArgs::state; gather1090.hip.h): four words, then kGatherShards shard words 32 words apart
+constexpr uint32_t kGatherShards = 32, kStateShard0 = 32, kStateWords = kStateShard0 + 32 * kGatherShards;
 
 constexpr uint32_t kSubRanges   = 4;  // work counters per XCD
 constexpr uint32_t kMaxXcd      = 16;
@@ -86,20 +89,38 @@ inline uint32_t scan_grid(const ScanArgs& a)
     return grid;
 }
 
-// Demodulation kernel (fills the raw record regions and the chunk directory; zeroes `total_and_overflow`).
+// The ordering pass of one scan (gather1090.hip.h): the scan's raw records, chunk directory and block sums -> the dense sorted arrays, with the
+// field decode.  Run by the next scan kernel on the stream (launch_scan1090 / launch_scan2400, `attached`) or on its own (launch_gather1090).
+struct GatherArgs
+{
+    const adsb_amd_record_t* chunk_records = nullptr; // ScanArgs::chunk_records, chunk_dir, block_sums, total_chunks, cap, chunks_per_buf of the scan to order
+    const uint32_t*          chunk_dir     = nullptr;
+    const uint32_t*          block_sums    = nullptr;
+    uint32_t                 nchunks       = 0;
+    uint32_t                 nblocks       = 0; // ceil(nchunks / kOrderChunks); 0: nothing to order
+    uint32_t                 cap           = 0;
+    uint32_t                 chunks_per_buf = 1;
+    adsb_amd_record_t*       dense         = nullptr; // the arrays to produce (any may be NULL)
+    adsb_amd_decoded_t*      decoded       = nullptr;
+    adsb_amd_packed_t*       packed        = nullptr;
+    uint32_t*                state         = nullptr; // the slot's kStateWords words, zero when the pass starts (its scan kernel zeroed them): see gather_units
+    uint32_t*                next_block_sums = nullptr; // the slot's other sum array (`next_entries` padded entries), zeroed for the slot's next scan
+    uint32_t                 next_entries  = 0;
+    uint32_t*                work_counters = nullptr; // the slot's work counters, zeroed for its next scan
+    unsigned long long*      host_word     = nullptr; // device address of 8 bytes of page-locked host memory (may be NULL): the pass's last finisher stores
+                                                      // count | (stamp << 1 | overflow flag) << 32 there, one system-scope store, after every record is in memory
+    uint32_t                 stamp         = 0;       // 31 bits
+    unsigned long long*      stamps        = nullptr; // measurement builds (ScanArgs::stamps)
+};
+
+// Demodulation kernel (fills the raw record regions and the chunk directory; zeroes `total_and_overflow`, the slot's GatherArgs::state, kStateWords words).
 // `start` / `stop` (either may be NULL): events that take the kernel's own start and end times -- they ride on the dispatch
 // (hipExtLaunchKernelGGL), where two hipEventRecord calls around the launch are packets of their own on the stream, 3-5 us each.
-hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
-// Ordering pass: the sorted gather into `dense` (+ field decode).  `total_and_overflow` is a device uint32_t[2]: {number of
-// records in dense, overflow flag}.  a.block_sums holds what the scan accumulated; `next_block_sums` (`next_entries` padded entries, the
-// slot's whole second array) is zeroed for the next scan of this slot, and so are the work counters.
-// dense / decoded / packed: the arrays to produce (any may be NULL)
-// `done` (may be NULL): event that takes the pass's end (riding on its dispatch like the scan's two)
-hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, adsb_amd_decoded_t* decoded, adsb_amd_packed_t* packed, uint32_t* next_block_sums,
-                            uint32_t next_entries, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t done = nullptr,
-                            unsigned long long* host_word = nullptr, uint32_t stamp = 0);
-// host_word (may be NULL): device address of 8 bytes of page-locked host memory; the pass's last workgroup stores
-// count | (stamp << 1 | overflow flag) << 32 there, one system-scope store (stamp: 31 bits)
+// `attached` (may be NULL): the ordering pass of an EARLIER scan on the same stream, done by this kernel's waves before their own work.
+hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr,
+                           const GatherArgs* attached = nullptr);
+// The ordering pass as a launch of its own.  `done` (may be NULL): event that takes the pass's end (riding on its dispatch like the scan's two).
+hipError_t launch_gather1090(const GatherArgs& ga, hipStream_t stream, hipEvent_t done = nullptr);
 // the field decoder of the ordering pass over an arbitrary device record array (parity helper)
 hipError_t launch_decode1090(const adsb_amd_record_t* rec, adsb_amd_decoded_t* out, size_t n, hipStream_t stream);
 
@@ -111,7 +132,8 @@ hipError_t launch_phase978(const uint8_t* iq, uint16_t* phi, size_t nsamples, co
 
 // ---- the 2.4 MS/s mode (scan2400.hip; definition: oracle/oracle2400.c).  Same ScanArgs, same raw records, same ordering pass.
 uint32_t   chunks_per_buffer_2400(uint32_t buf_samples);
-hipError_t launch_scan2400(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+hipError_t launch_scan2400(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start = nullptr, hipEvent_t stop = nullptr,
+                           const GatherArgs* attached = nullptr);
 
 // host-side table builders (exact integer / polynomial arithmetic, no reference text)
 void build_crc_table(uint32_t* tab /* 112 */);

@@ -36,6 +36,7 @@
 
 #include "decode1090.h"
 #include "scan1090.h"
+#include "gather1090.hip.h"
 #include "scan_common.hip.h"
 
 namespace adsb_amd
@@ -483,7 +484,7 @@ __device__ __forceinline__ void queue_survivors(uint64_t surv, uint32_t first, i
 // Measurement builds (diag.hip.h, tools/parts.sh) compile the later parts out: 0 = the loads alone, 1 = + window -> s, 2 = + stage 1,
 // 3 = + survivor queue and stage 2, more = everything (the product).
 constexpr int kParts = diag::kParts;
-__global__ __launch_bounds__(64, 4) void scan1090_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow)
+__global__ __launch_bounds__(64, 4) void scan1090_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow, GatherArgs ga)
 {
     // the interleaved image of s (scan1090.h), the slot of the sample in front of the chunk, then the survivor queue.  The queue
     // doubles as the landing zone of the fast demodulation path's reads beyond a window (lanes 48..63 have no second bit; what
@@ -497,7 +498,10 @@ __global__ __launch_bounds__(64, 4) void scan1090_kernel(ScanArgs a, uint32_t* _
     const LaneTables lt   = load_lane_tables(a.crc_tab, lane);
     const FastConsts fc   = fast_consts(lane);
     const uint32_t   tile_addr = lds_address(tile32), queue_addr = lds_address(queue);
-    if (blockIdx.x == 0 && lane < 2) total_overflow[lane] = 0; // {record total, overflow flag}: filled by the ordering pass that follows in-stream
+    if (blockIdx.x == 0) gather_state_zero(total_overflow, (uint32_t)lane); // this slot's ordering state (GatherArgs::state): its pass runs in a later kernel on the stream
+    // Round 6: the ordering pass of the OTHER slot's scan -- an earlier kernel on this stream -- by a quarter of this kernel's waves, a block each, before their
+    // own chunks (gather1090.hip.h).  The image area is free until then.
+    gather_in_front(ga, a.ncu, *reinterpret_cast<GatherLds*>(tile32), (uint32_t)lane);
 
     // XCD-aware chunk order, one work counter per sub-range: scan_common.hip.h (WorkRange).  (Round 1 also offset the waves of a
     // SIMD in time at the start so that their phases would not coincide; with the priority hint below that costs 1.7 %.)
@@ -735,207 +739,15 @@ __global__ __launch_bounds__(64, 4) void scan1090_kernel(ScanArgs a, uint32_t* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// The field decoder of decode1090.h (decode_record) for the ordering pass: the same function of the message, written for a vector unit
-// that runs every branch some lane of the wave takes (a wave of 64 records has every kind of message in it, so the byte-wise version
-// cost the pass all its branches one after the other: 4.4 of its 13 us).  Straight-line bit-field arithmetic on the message as big-endian
-// words B0..B2 (B0 = bytes 0-3, first byte on top), one select per result at the end; the identification's eight characters come out of
-// a 64-byte table in LDS (eight byte reads instead of eight chains of comparisons).  Checked against the host build record by
-// record (tests: the 4.2 M velocity pairs, every identification character, random records of every DF).
+// The ordering pass on its own (gather1090.hip.h has the routine and the reasons): for a scan that no later scan kernel on its stream orders --
+// the last step of a loop, a live buffer, a serial caller.  One wave per workgroup, blocks drawn from the slot's counter.
 // ---------------------------------------------------------------------------------------------
-struct FieldsDev
+__global__ __launch_bounds__(64) void gather_kernel(GatherArgs ga)
 {
-    uint32_t head;     // kind | metype << 8 | mesub << 16 | odd << 24 (adsb_amd_decoded_t's first four bytes)
-    uint32_t altitude; // int32
-    uint32_t a, b;
-};
-__device__ __forceinline__ void ais_table_init(uint8_t* tab /* 64, LDS */, uint32_t t)
-{
-    if (t < 64u) tab[t] = (uint8_t)ais_char(t);
-}
-__device__ __forceinline__ FieldsDev decode_fields_dev(uint32_t B0, uint32_t B1, uint32_t B2, uint32_t df, const uint8_t* ais /* LDS */)
-{
-    const uint32_t metype = B1 >> 27, mesub = (B1 >> 24) & 7u;
-    // DF0/4/20: the 13-bit AC field, bytes 2-3 (:440-466)
-    const uint32_t ac13 = B0 & 0x1FFFu;
-    const int      n13  = (int)(((ac13 & 0x1F80u) >> 2) | ((ac13 & 0x20u) >> 1) | (ac13 & 0xFu));
-    const int      alt13 = ((ac13 & 0x40u) || !(ac13 & 0x10u)) ? 0 : n13 * 25 - 1000;
-    // airborne position (:622-630, 470-486): AC12 = bytes 5 and 6's high nibble, F flag, 17-bit raw latitude and longitude
-    const uint32_t ac12  = (B1 >> 12) & 0xFFFu;
-    const int      alt12 = (ac12 & 0x10u) ? (int)(((ac12 >> 5) << 4) | (ac12 & 0xFu)) * 25 - 1000 : 0;
-    const uint32_t lat   = ((B1 & 0x3FFu) << 7) | (B2 >> 25), lon = (B2 >> 8) & 0x1FFFFu, odd = (B1 >> 10) & 1u;
-    // airborne velocity (:631-660)
-    const int ew = (int)((B1 >> 8) & 0x3FFu), ns = (int)(((B1 & 0x7Fu) << 3) | (B2 >> 29));
-    const int n  = ns * ns + ew * ew;
-    int       v  = (int)__builtin_sqrtf((float)n); // within one of the integer square root (n < 2^21 is exact in a float)
-    v -= (v * v > n) ? 1 : 0;
-    v += ((v + 1) * (v + 1) <= n) ? 1 : 0;
-    const int h = v ? heading_of((B1 & (1u << 18)) ? -ew : ew, (B1 & 0x80u) ? -ns : ns) : 0;
-    // identification (:608-619): eight 6-bit characters in bytes 5-10
-    const uint32_t c03 = B1 & 0xFFFFFFu, c47 = B2 >> 8;
-    const uint32_t ia = (uint32_t)ais[c03 >> 18] | ((uint32_t)ais[(c03 >> 12) & 63u] << 8) | ((uint32_t)ais[(c03 >> 6) & 63u] << 16) | ((uint32_t)ais[c03 & 63u] << 24);
-    const uint32_t ib = (uint32_t)ais[c47 >> 18] | ((uint32_t)ais[(c47 >> 12) & 63u] << 8) | ((uint32_t)ais[(c47 >> 6) & 63u] << 16) | ((uint32_t)ais[c47 & 63u] << 24);
-
-    const bool is_alt = df == 0u || df == 4u || df == 20u, es = df == 17u;
-    const bool is_id = es && metype - 1u < 4u, is_pos = es && metype - 9u < 10u, is_vel = es && metype == 19u && mesub - 1u < 2u;
-    FieldsDev  f;
-    const uint32_t kind = is_alt ? (uint32_t)ADSB_AMD_K_ALTITUDE : is_id ? (uint32_t)ADSB_AMD_K_IDENT : is_pos ? (uint32_t)ADSB_AMD_K_POSITION : is_vel ? (uint32_t)ADSB_AMD_K_VELOCITY : 0u;
-    f.head     = kind | (metype << 8) | (mesub << 16) | ((is_pos ? odd : 0u) << 24);
-    f.altitude = (uint32_t)(is_alt ? alt13 : is_pos ? alt12 : 0);
-    f.a        = is_id ? ia : is_pos ? lat : is_vel ? (uint32_t)v : 0u;
-    f.b        = is_id ? ib : is_pos ? lon : is_vel ? (uint32_t)h : 0u;
-    return f;
-}
-
-// ---------------------------------------------------------------------------------------------
-// ordering pass: one launch.  A workgroup takes 256 consecutive chunks: exclusive prefix over their record counts (the records of
-// all earlier workgroups come from block_sums, which the scan kernels accumulated chunk by chunk), then ONE LANE PER RECORD moves the
-// records into the dense arrays sorted by (offset, pass).
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t kOrderBlock   = 256;  // chunks per workgroup of the ordering pass
-constexpr uint32_t kOrderThreads = 640; // its threads = records it moves per trip (a block of a quiet band holds ~550); two workgroups per CU
-static_assert(kOrderThreads % 64 == 0 && kOrderThreads >= kOrderBlock && kOrderThreads <= 1024, "whole waves, at least the chunk threads");
-
-// Round 4.  Until then a thread walked its chunk's records one after the other -- load the record, count the chunk's smaller keys, decode,
-// store, next -- and a wave took as long as its longest chunk: seven dependent trips of a memory round trip each where the average chunk
-// has two records, 28-31 us for 18 MB.  Now the chunk threads only publish where their records start (LDS), every record gets a lane of
-// its own (`owner`: which chunk a record of the block belongs to, scattered by the chunk threads), the lane fetches its record and, in
-// the same breath, the keys of the chunk's other records (four at a time), and the whole block is done after one round trip.
-__global__ __launch_bounds__(kOrderThreads) void gather_sorted_kernel(const adsb_amd_record_t* __restrict__ chunk_records,
-                                                            const uint32_t* __restrict__ chunk_dir, const uint32_t* __restrict__ block_sums,
-                                                            uint32_t nchunks, uint32_t nblocks, uint32_t cap, uint32_t chunks_per_buf,
-                                                            adsb_amd_record_t* __restrict__ dense, adsb_amd_decoded_t* __restrict__ decoded,
-                                                            adsb_amd_packed_t* __restrict__ packed, uint32_t* __restrict__ total_overflow,
-                                                            uint32_t* __restrict__ next_block_sums,
-                                                            uint32_t next_entries, uint32_t* __restrict__ work_counters, unsigned long long* stamps,
-                                                            unsigned long long* host_word, uint32_t stamp_no)
-{
-    constexpr uint32_t kWaves = kOrderThreads / 64;
-    stamp(stamps, 2);
-    struct StampOut
-    {
-        unsigned long long* st;
-        __device__ ~StampOut() { stamp(st, 3); }
-    } stamp_on_exit{stamps};
-    __shared__ uint32_t before_w[kWaves], count_w[kOrderBlock / 64];
-    __shared__ uint32_t cstart[kOrderBlock + 1]; // first record of each chunk among the block's records, and their total
-    __shared__ uint8_t  owner[kOrderThreads];    // chunk (within the block) of record `trip base + t`
-    __shared__ uint8_t  ais[64];                 // the identification message's character set (decode_fields_dev)
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    ais_table_init(ais, tid); // (the barrier behind the prefix sums comes before its first reader)
-    // housekeeping for the next scan of this slot: its block sums (the other of two arrays, all of it: the next input may be larger
-    // than this one) and the work counters start from zero
-    for (uint32_t k = blockIdx.x * kOrderThreads + tid; k < 2u * next_entries; k += nblocks * kOrderThreads)
-        next_block_sums[(k >> 1) * kSumStride + (k & 1u)] = 0;
-    if (blockIdx.x == 0 && tid < kWorkCounters) work_counters[tid * kCounterStride] = 0;
-    if (tid == 0 && block_sums[blockIdx.x * kSumStride + 1]) atomicOr(&total_overflow[1], 1u); // some chunk of this block overflowed its region
-    // records in earlier blocks, and this block's chunk counts
-    uint32_t before = 0;
-    for (uint32_t b = tid; b < blockIdx.x; b += kOrderThreads) before += block_sums[b * kSumStride];
-    // the last workgroup also tells the host (host_word): it reads every block's overflow flag for that
-    bool any_over = false;
-    if (host_word && blockIdx.x == nblocks - 1)
-        for (uint32_t b = tid; b < nblocks; b += kOrderThreads) any_over = any_over || block_sums[b * kSumStride + 1] != 0;
-    const uint32_t c  = blockIdx.x * kOrderBlock + tid;
-    const uint32_t n  = (tid < kOrderBlock && c < nchunks) ? chunk_dir[c] : 0u; // records kept
-    before            = wave_incl_scan_add(before);
-    if (lane == 63) before_w[wave] = before;
-    uint32_t incl = 0;
-    if (tid < kOrderBlock)
-    { // (whole waves: kOrderBlock is a multiple of 64)
-        incl = wave_incl_scan_add(n);
-        if (lane == 63) count_w[wave] = incl;
-    }
-    __syncthreads();
-    uint32_t base = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < kWaves; w++) base += before_w[w];
-    uint32_t tot = 0, mine = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < kOrderBlock / 64; w++)
-    {
-        const uint32_t t = count_w[w];
-        if (w < wave) mine += t;
-        tot += t;
-    }
-    const uint32_t excl = incl - n + mine;
-    if (tid < kOrderBlock) cstart[tid] = excl;
-    if (tid == 0) cstart[kOrderBlock] = tot;
-    if (blockIdx.x == nblocks - 1 && tid == 0) total_overflow[0] = base + tot;
-    if (host_word && blockIdx.x == nblocks - 1)
-    { // (all waves of the workgroup come here: the sync is not divergent)
-        const int over = __syncthreads_or(any_over ? 1 : 0);
-        if (tid == 0)
-            __hip_atomic_store(host_word, (unsigned long long)(base + tot) | ((unsigned long long)(((stamp_no & 0x7FFFFFFFu) << 1) | (over ? 1u : 0u)) << 32),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if constexpr (diag::kOrderParts == 1) return; // measurement builds (no records): 1 = the prefix only, 2 = + fetch and store, 3 = + ranks
-
-    for (uint32_t trip = 0; trip < tot; trip += kOrderThreads)
-    {
-        if (trip) __syncthreads(); // the previous trip's readers of `owner` are done
-        if (tid < kOrderBlock)
-            for (uint32_t i = (excl < trip ? trip - excl : 0u); i < n && excl + i < trip + kOrderThreads; i++) owner[excl + i - trip] = (uint8_t)tid;
-        __syncthreads();
-        const uint32_t r = trip + tid; // this lane's record among the block's
-        if (r >= tot) continue;
-        const uint32_t cc = owner[tid], first = cstart[cc], nn = cstart[cc + 1] - first, i = r - first;
-        const uint32_t ch = blockIdx.x * kOrderBlock + cc; // the chunk
-        const uint4*   src = reinterpret_cast<const uint4*>(chunk_records + (uint64_t)ch * cap);
-        const uint4    lo  = src[2 * i];
-        uint4          hi  = src[2 * i + 1];
-        // rank among the chunk's records by (offset, pass): their keys four at a time (a chunk seldom has more)
-        const uint32_t key = (lo.x << 1) | ((lo.y >> 16) & 1u);
-        uint32_t       rank = 0;
-        if constexpr (diag::kOrderParts == 2) rank = i;
-        else
-        for (uint32_t k0 = 0; k0 < nn; k0 += 4)
-        {
-            uint2 q[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) q[k] = *reinterpret_cast<const uint2*>(&src[2 * (k0 + k < nn ? k0 + k : i)]);
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) rank += (((q[k].x << 1) | ((q[k].y >> 16) & 1u)) < key) ? 1u : 0u;
-        }
-        const uint32_t buffer = ch / chunks_per_buf;
-        const size_t   out    = (size_t)base + first + rank;
-        // raw -> adsb_amd_record_t: apply the 1-bit repair, order the bytes, pull the address out
-        const uint32_t df = lo.y & 0xFFu, nbits = (lo.y >> 8) & 0xFFu, flags = (lo.y >> 16) & 0xFFu;
-        const int      errorbit = (int)(lo.y >> 24) - 1;
-        if (errorbit >= 0)
-        {
-            const uint32_t m = 1u << (errorbit & 31);
-            if (errorbit < 32) hi.x ^= m;
-            else if (errorbit < 64) hi.y ^= m;
-            else if (errorbit < 96) hi.z ^= m;
-            else hi.w ^= m;
-        }
-        // the message as big-endian words (first bit on top) and as bytes in memory order
-        const uint32_t B0 = __builtin_bitreverse32(hi.x), B1 = __builtin_bitreverse32(hi.y), B2 = __builtin_bitreverse32(hi.z), B3 = __builtin_bitreverse32(hi.w);
-        const uint32_t m0 = __builtin_bswap32(B0), m1 = __builtin_bswap32(B1), m2 = __builtin_bswap32(B2), m3 = __builtin_bswap32(B3); // bytes 0-3, 4-7, 8-11, 12-13
-        const uint32_t addr = (flags & ADSB_AMD_F_NEEDS_ICAO) ? lo.z : (B0 & 0xFFFFFFu);
-        uint4 o0;
-        o0.x = buffer;
-        o0.y = lo.x;
-        o0.z = addr;
-        o0.w = (lo.w & 0xFFFFu) | (nbits << 16) | (((uint32_t)errorbit & 0xFFu) << 24);
-        if (dense)
-        {
-            uint4* o = reinterpret_cast<uint4*>(dense + out);
-            o[0]     = o0;
-            o[1]     = make_uint4(df | (flags << 8) | (m0 << 16), (m0 >> 16) | (m1 << 16), (m1 >> 16) | (m2 << 16), (m2 >> 16) | (m3 << 16));
-        }
-        // the stateless half of DecodeModesMessage, so that the host's sequential pass decodes nothing
-        FieldsDev d{};
-        if constexpr (diag::kOrderParts <= 3) d.a = B1 ^ key;
-        else d = decode_fields_dev(B0, B1, B2, df, ais);
-        if (decoded) *reinterpret_cast<uint4*>(decoded + out) = make_uint4(d.head, d.altitude, d.a, d.b);
-        if (packed)
-        { // the record's first sixteen bytes, then df, flags, kind, odd and the decoded values (adsb_amd_packed_t)
-            uint4* o = reinterpret_cast<uint4*>(packed + out);
-            o[0]     = o0;
-            o[1]     = make_uint4(df | (flags << 8) | ((d.head & 0xFFu) << 16) | (d.head & 0xFF000000u), d.altitude, d.a, d.b);
-        }
-    }
+    __shared__ __attribute__((aligned(16))) GatherLds lds;
+    stamp(ga.stamps, 2);
+    gather_units(ga, blockIdx.x, gridDim.x, 4u, lds, threadIdx.x); // (a quarter block per wave: nothing else runs beside this kernel)
+    stamp(ga.stamps, 3);
 }
 
 // parity helper: the same decoder over an arbitrary record array
@@ -982,13 +794,14 @@ __global__ __launch_bounds__(256) void phase978_kernel(const uint8_t* __restrict
 
 } // namespace
 
-hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start, hipEvent_t stop)
+hipError_t launch_scan1090(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const GatherArgs* attached)
 {
-    if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
+    if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, kStateWords * sizeof(uint32_t), stream);
     // persistent single-wave workgroups: enough to fill every CU at the LDS-limited occupancy (16 per CU)
-    const uint32_t grid = scan_grid(a);
-    if (start || stop) hipExtLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, start, stop, 0, a, total_and_overflow); // (either may be NULL)
-    else hipLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
+    const uint32_t   grid = scan_grid(a);
+    const GatherArgs ga   = attached ? *attached : GatherArgs{};
+    if (start || stop) hipExtLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, start, stop, 0, a, total_and_overflow, ga); // (either may be NULL)
+    else hipLaunchKernelGGL(scan1090_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow, ga);
     return hipGetLastError();
 }
 
@@ -999,21 +812,12 @@ hipError_t launch_decode1090(const adsb_amd_record_t* rec, adsb_amd_decoded_t* o
     return hipGetLastError();
 }
 
-hipError_t launch_order1090(const ScanArgs& a, adsb_amd_record_t* dense, adsb_amd_decoded_t* decoded, adsb_amd_packed_t* packed, uint32_t* next_block_sums,
-                            uint32_t next_entries, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t done, unsigned long long* host_word, uint32_t stamp)
+hipError_t launch_gather1090(const GatherArgs& ga, hipStream_t stream, hipEvent_t done)
 {
-    if (a.total_chunks == 0) return hipSuccess;
-    static_assert(kOrderBlock == kOrderChunks, "one block-sum entry per workgroup of the ordering pass");
-    const uint32_t nblocks = (a.total_chunks + kOrderBlock - 1u) / kOrderBlock;
-    unsigned long long* const stamps = a.stamps;
-    if (done)
-        hipExtLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderThreads), 0, stream, nullptr, done, 0, a.chunk_records, a.chunk_dir, a.block_sums,
-                       a.total_chunks, nblocks, a.cap, a.chunks_per_buf, dense, decoded, packed, total_and_overflow, next_block_sums, next_entries, a.work_counters,
-                       stamps, host_word, stamp);
-    else
-        hipLaunchKernelGGL(gather_sorted_kernel, dim3(nblocks), dim3(kOrderThreads), 0, stream, a.chunk_records, a.chunk_dir, a.block_sums,
-                       a.total_chunks, nblocks, a.cap, a.chunks_per_buf, dense, decoded, packed, total_and_overflow, next_block_sums, next_entries, a.work_counters,
-                       stamps, host_word, stamp);
+    if (ga.nblocks == 0) return hipSuccess;
+    const uint32_t units = ga.nblocks * 4u /* kGatherSplit */, grid = units < 8192u ? units : 8192u;
+    if (done) hipExtLaunchKernelGGL(gather_kernel, dim3(grid), dim3(64), 0, stream, nullptr, done, 0, ga);
+    else hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(64), 0, stream, ga);
     return hipGetLastError();
 }
 

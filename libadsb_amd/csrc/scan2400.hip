@@ -31,6 +31,7 @@
 #include <stdint.h>
 
 #include "scan1090.h"
+#include "gather1090.hip.h"
 #include "scan_common.hip.h"
 
 namespace adsb_amd
@@ -313,7 +314,7 @@ __device__ __forceinline__ h8_t halves_to_f16(uint4 x)
     return __builtin_bit_cast(h8_t, u4_t{pair_to_f16(x.x), pair_to_f16(x.y), pair_to_f16(x.z), pair_to_f16(x.w)});
 }
 
-__global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow)
+__global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* __restrict__ total_overflow, GatherArgs ga)
 {
     __shared__ __attribute__((aligned(16))) uint16_t img16[kImgHalves];
     __shared__ __attribute__((aligned(16))) uint16_t gatemap[kChunk / 16]; // bit p of the map: position p passes the prefilter (64 x 64 bits)
@@ -331,7 +332,10 @@ __global__ __launch_bounds__(64, 4) void scan2400_kernel(ScanArgs a, uint32_t* _
     typedef int sw_t __attribute__((ext_vector_type(4)));
     const sw_t score_w = *reinterpret_cast<const sw_t*>(kScoreTable.w[lane]); // the scores' weights (A operand), four registers for the whole launch
     const int tl = lane & 15, rw = lane >> 4; // scoring: row rw of 16 lanes takes a survivor, lane tl of the row its window sample tl
-    if (blockIdx.x == 0 && lane < 2) total_overflow[lane] = 0; // {record total, overflow flag}: filled by the ordering pass that follows in-stream
+    if (blockIdx.x == 0) gather_state_zero(total_overflow, (uint32_t)lane); // this slot's ordering state (GatherArgs::state): its pass runs in a later kernel on the stream
+    // the ordering pass of the other slot's scan, by a quarter of this kernel's waves, a block each, before their own chunks (gather1090.hip.h; the image area is free until then)
+    static_assert(sizeof(img16) >= sizeof(GatherLds), "the ordering pass's scratch fits in the image area");
+    gather_in_front(ga, a.ncu, *reinterpret_cast<GatherLds*>(img16), (uint32_t)lane);
     if (lane < kImgPad) img16[lane] = 0; // the halves in front of the image: zero weights, but they go through the multiplier
 
     // persistent waves, chunk order and work counters as in scan1090_kernel (scan_common.hip.h)
@@ -594,13 +598,14 @@ uint32_t chunks_per_buffer_2400(uint32_t buf_samples)
     return (buf_samples - (uint32_t)kSpan24 + (uint32_t)kChunk - 1) / (uint32_t)kChunk;
 }
 
-hipError_t launch_scan2400(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start, hipEvent_t stop)
+hipError_t launch_scan2400(const ScanArgs& a, uint32_t* total_and_overflow, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const GatherArgs* attached)
 {
-    if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, 2 * sizeof(uint32_t), stream);
+    if (a.total_chunks == 0) return hipMemsetAsync(total_and_overflow, 0, kStateWords * sizeof(uint32_t), stream);
     // persistent single-wave workgroups, as many as the LDS lets a CU hold (16 x 10 208 bytes), in whole (XCD, sub-range) units
-    const uint32_t grid = scan_grid(a);
-    if (start || stop) hipExtLaunchKernelGGL(scan2400_kernel, dim3(grid), dim3(64), 0, stream, start, stop, 0, a, total_and_overflow); // (either may be NULL)
-    else hipLaunchKernelGGL(scan2400_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow);
+    const uint32_t   grid = scan_grid(a);
+    const GatherArgs ga   = attached ? *attached : GatherArgs{};
+    if (start || stop) hipExtLaunchKernelGGL(scan2400_kernel, dim3(grid), dim3(64), 0, stream, start, stop, 0, a, total_and_overflow, ga); // (either may be NULL)
+    else hipLaunchKernelGGL(scan2400_kernel, dim3(grid), dim3(64), 0, stream, a, total_and_overflow, ga);
     return hipGetLastError();
 }
 

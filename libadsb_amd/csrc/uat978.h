@@ -69,6 +69,7 @@ struct UatArgs
     const uint16_t* lut; // 65536-entry phase LUT
     const RsTables* rs_tables;
     uint64_t        nsamples;
+    uint32_t        ncu; // compute units of the device (read when the handle is made; 0: 256)
     int             phases_given;
     uint64_t*       signs; // phases path only: ceil(nsamples / 64) + 2 words
     uint32_t*       cand;

@@ -1122,9 +1122,11 @@ __device__ unsigned long long g_uat_diag[2][8]; // [kind][phase]; phase 7 = posi
 #endif
 enum { kDiagStage = 0, kDiagSync, kDiagSlice, kDiagSyndromes, kDiagDecode, kDiagMoreTiles, kDiagOutput };
 
-// Waves of a demodulating workgroup: they share the folded phase table (32 KB) and the Reed-Solomon tables and have ~4 KB each of their own.
-// Two workgroups per CU: 2 x (32 KB + 0.75 KB + 8 x 4 KB) = 131 KB, which leaves room for a decision kernel's workgroup (20 KB) of another call.
+// Waves of a demodulating workgroup: they share the folded phase table (32 KB) and the Reed-Solomon tables (768 B) and have 4 032 B each of their own.
+// Two workgroups per CU: 2 x (32 768 + 768 + 12 x 4 032) = 163 840 bytes, ALL of a CU's LDS (the static_assert in the kernel holds it there: one byte
+// more and a CU holds one workgroup, half the waves, without any error).  Nothing else that needs LDS runs on a CU while two of these are resident.
 constexpr int kUatDemodWaves = 12;
+constexpr size_t kCuLdsBytes = 160 * 1024;
 template <bool PHASES_GIVEN>
 __global__ __launch_bounds__(64 * kUatDemodWaves, 6) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
                                                        const RsTables* __restrict__ rs_tables, const uint32_t* __restrict__ cand, uint32_t ncand,
@@ -1144,6 +1146,7 @@ __global__ __launch_bounds__(64 * kUatDemodWaves, 6) void uat_demod_kernel(const
     __shared__ RsTables T;
     __shared__ __attribute__((aligned(16))) uint16_t folded[PHASES_GIVEN ? 2 : kUatFoldedEntries];
     __shared__ WaveArea areas[kUatDemodWaves];
+    static_assert(2 * (sizeof(RsTables) + sizeof(uint16_t) * kUatFoldedEntries + sizeof(WaveArea) * kUatDemodWaves) <= kCuLdsBytes, "two demodulating workgroups per CU");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (said to be uniform: the wave's LDS addresses stay on the scalar side)
     for (int i = threadIdx.x; i < (int)sizeof(RsTables) / 4; i += 64 * kUatDemodWaves) reinterpret_cast<uint32_t*>(&T)[i] = reinterpret_cast<const uint32_t*>(rs_tables)[i];
     if constexpr (!PHASES_GIVEN)
@@ -1945,9 +1948,8 @@ hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, bool ordered, h
     if (ncand == 0) return hipSuccess;
     uint32_t* const work = a.demod_work;
     const uint32_t nranges = ncand >= 4096 ? kUatDemodRanges : 1u;
-    // one wave per match up to what the device holds at once (two workgroups per CU, 256 CUs: the waves draw tickets from there on)
-    constexpr uint32_t kResidentWaves = 2 * 256 * kUatDemodWaves;
-    
+    // one wave per match up to what the device holds at once (two workgroups per CU: the waves draw tickets from there on)
+    const uint32_t kResidentWaves = 2 * (a.ncu ? a.ncu : 256u) * kUatDemodWaves;
     uint32_t waves = ncand > kResidentWaves ? kResidentWaves : ncand;
     waves          = ((waves + nranges - 1) / nranges) * nranges;
     const uint32_t g = (waves + kUatDemodWaves - 1) / kUatDemodWaves;

@@ -149,6 +149,7 @@ struct Pinned
 struct adsb_amd_uat
 {
     int         device = 0;
+    uint32_t    ncu    = 256; // compute units of the device (hipDeviceAttributeMultiprocessorCount, read in init)
     hipStream_t stream = nullptr;
     hipEvent_t  ev[6]  = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // What the demodulation pass leaves behind -- records, payloads, uplink payloads, the frames behind frames: 7 MB per GiB -- goes to the host on
@@ -245,6 +246,10 @@ struct adsb_amd_uat
     int init()
     {
         UAT_HIP(hipSetDevice(device));
+        {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) ncu = (uint32_t)n;
+        }
         UAT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         UAT_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         for (auto& e : ev) UAT_HIP(hipEventCreate(&e));
@@ -371,7 +376,7 @@ struct adsb_amd_uat
     UatArgs args(const uint16_t* in, uint64_t n, bool phases_given) const
     {
         UatArgs a{};
-        a.in = in, a.lut = lut_d, a.rs_tables = rs_d, a.nsamples = n, a.phases_given = phases_given ? 1 : 0;
+        a.in = in, a.lut = lut_d, a.rs_tables = rs_d, a.nsamples = n, a.phases_given = phases_given ? 1 : 0, a.ncu = ncu;
         a.signs = signs_d, a.cand = cand_d, a.cand_cap = cand_cap, a.counts = counts_d; // demod_on_device points a.cand at sorted_d
         a.recs = recs_d, a.payloads = pay_d, a.uplink_payloads = up_d, a.uplink_cap = up_cap, a.demod_work = demod_work_d;
         if (!phases_given) a.bin_fill = bin_fill_d[bin_phase], a.bin_fill_next = bin_fill_d[bin_phase ^ 1], a.bins_cap = bins_cap, a.bin_slots = bin_slots_d;

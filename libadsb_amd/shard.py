@@ -273,11 +273,12 @@ class NodeGather:
     def flush(self):
         """Write the headers noted so far into this rank's slot of the control page, oldest first, each once its event has completed
         (waits for it: by the time this is called -- the rank's next step, or the end of a loop -- the copy is long done)."""
-        posted, self._posted = self._posted, []
-        for step, count, first, event in posted:
-            if event is not None:
+        while self._posted:
+            step, count, first, event = self._posted[0]  # (taken off the list only once its header is written: a wait or a write that raises
+            if event is not None:                         # leaves it, and everything behind it, noted for the next flush or close)
                 event.synchronize()
             self._L.adsb_amd_shm_post_header(self._word(self._slot(self.rank, step)), count, first, self.rank, step)
+            self._posted.pop(0)
 
     def acquire(self, step):
         """Before this rank's segment of `step` is written: wait until the root has finished reading step - 2 (same segment)."""
@@ -467,3 +468,40 @@ def uat_run_parts(handles, device_ptr, nsamples, offset=0, collect=True):
             consumed = done + w0
     return frames, consumed
 
+
+def uat_chain_step(u, dist, word, rank, world, part, window_ptr, collect=False, phase=None):
+    """One rank's share of ONE process_buffer over a stream cut over the ranks (uat_part): the heavy half of its part at once (part_scan),
+    then the 8-byte "where the loop stands" from the rank before (recv), the decisions and up-calls of its own part (part_finish), and the
+    loop's position on to the rank behind (send).  `word`: a one-element int64 tensor on the device the process group's backend moves (cuda for
+    nccl, cpu for gloo).  A rank whose part is empty (the stream closed before it) passes the word on unchanged.  A failure travels down the
+    chain as -1, so that no later rank sits in recv until a watchdog fires.  Returns (frames, samples consumed counted from the stream's start --
+    meaningful on the closing rank --, the loop's position after this part)."""
+    w0, w1, b, e, last = part
+    mark = phase or (lambda *_: None)
+    mark("part scan")
+    if e > b:
+        u.part_scan(window_ptr, w1 - w0)
+    at = 0
+    if rank > 0:
+        mark("waiting for the rank before")
+        dist.recv(word, src=rank - 1)
+        at = int(word.item())
+        if at < 0:
+            if rank < world - 1:
+                dist.send(word, dst=rank + 1)
+            raise RuntimeError("rank %d: the part of an earlier rank failed" % rank)
+    mark("part finish")
+    frames, done, exit_bit = [], 0, at
+    if e > b:
+        try:
+            frames, exit_local, done = u.part_finish(b - w0, e - w0, max(at - w0 // 2, 0), last, offset=w0, collect=collect)
+        except Exception:
+            if rank < world - 1:
+                word[0] = -1
+                dist.send(word, dst=rank + 1)
+            raise
+        exit_bit = exit_local + w0 // 2
+    if rank < world - 1:
+        word[0] = exit_bit
+        dist.send(word, dst=rank + 1)
+    return frames, done + w0, exit_bit

@@ -251,6 +251,60 @@ for NBUF in (11, 5):
             H.assert_records_equal(got, want)
         else:
             assert got is None
+# ---- the UAT workload's partition of configs[3]'s kind of job (bench.py --workload uat978 --gpus 8: one_stream_cut_over_ranks): ONE stream cut
+# over eight ranks (shard.uat_part) and the chain that carries the loop's position from rank to rank (shard.uat_chain_step, the very function
+# bench.py runs), with a stand-in for the GPU handle that records what it is asked: the product has no CPU path, so what is rehearsed here is the
+# arithmetic of the cut, the order of the chain, the pass-through of a rank without a part and the way a failure travels down the chain.
+import torch
+LEAD, TAIL = shard.UAT_LEAD_SAMPLES, shard.UAT_TAIL_SAMPLES
+for NS in (8 * (1 << 29), 8 * (1 << 29) + 12345, 5 * TAIL + 999, 2 * TAIL + 64, 1000):  # 8 x 1 GiB of u8 IQ; a ragged one; streams too short for eight parts
+    parts = [shard.uat_part(NS, r, world) for r in range(world)]
+    own = [(b, e) for _, _, b, e, _ in parts if e > b]
+    assert own[0][0] == 0 and own[-1][1] == NS and all(own[k][1] == own[k + 1][0] for k in range(len(own) - 1)), (NS, own)  # the own ranges tile the stream
+    assert sum(1 for p in parts if p[4]) == 1 and all(p[2] == p[3] == NS for p in parts[[p[4] for p in parts].index(True) + 1:])  # one closing part, nothing behind it
+    for w0, w1, b, e, last in parts:
+        if e > b:  # what adsb_amd_uat_part_finish asks of a window
+            assert b %% 64 == 0 and (b == 0 or b - w0 >= 64) and (last and w1 == NS or not last and w1 - e >= TAIL) and 0 <= w0 <= b <= e <= w1 <= NS
+    if NS == 8 * (1 << 29):
+        assert [(b, e) for _, _, b, e, _ in parts] == [(r << 29, (r + 1) << 29) for r in range(8)]  # 1 GiB of IQ per GPU, no remainder
+
+    class Stand:
+        # exit position = own end in bits + 7 * (rank + 1): behind the part, different on every rank, so a word taken from the wrong rank shows
+        def __init__(self, fail=False):
+            self.calls, self.fail = [], fail
+        def part_scan(self, ptr, n):
+            self.calls.append(('scan', ptr, n))
+        def part_finish(self, own_begin, own_end, entry, last, offset=0, collect=True):
+            self.calls.append(('finish', own_begin, own_end, entry, last, offset))
+            if self.fail:
+                raise RuntimeError('stand-in failure')
+            return [(rank, entry + offset // 2)], (own_end + offset) // 2 + 7 * (rank + 1) - offset // 2, own_end
+    word = torch.zeros(1, dtype=torch.int64)
+    u = Stand()
+    w0, w1, b, e, last = parts[rank]
+    frames, consumed, exit_bit = shard.uat_chain_step(u, dist, word, rank, world, parts[rank], 4096 + 2 * w0)
+    exits = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(exits, torch.tensor([exit_bit], dtype=torch.int64))
+    exits = [int(x.item()) for x in exits]
+    before = 0 if rank == 0 else exits[rank - 1]
+    if e > b:
+        assert u.calls[0] == ('scan', 4096 + 2 * w0, w1 - w0) and u.calls[1] == ('finish', b - w0, e - w0, max(before - w0 // 2, 0), last, w0), u.calls
+        assert frames == [(rank, max(before - w0 // 2, 0) + w0 // 2)] and exit_bit == e // 2 + 7 * (rank + 1) and consumed == e
+    else:
+        assert u.calls == [] and frames == [] and exit_bit == before  # no part: the word goes through unchanged
+    dist.barrier()
+    # a rank whose part fails: every rank behind it raises at once (-1 down the chain), the ranks before it are not disturbed
+    nparts = len(own)
+    bad = nparts // 2
+    u = Stand(fail=rank == bad)
+    try:
+        shard.uat_chain_step(u, dist, word, rank, world, parts[rank], 4096 + 2 * w0)
+        raised = False
+    except RuntimeError as ex:
+        raised = True
+        assert ('stand-in' in str(ex)) == (rank == bad)
+    assert raised == (rank >= bad), (NS, rank, bad, raised)
+    dist.barrier()
 import glob
 assert not glob.glob('/dev/shm/libadsb_amd_gather_*w8-*'), 'no file may be left behind'
 if rank == 0:

@@ -249,6 +249,43 @@ def test_full_size_1gib_equals_oracle_on_every_buffer(scanner):
     H.assert_records_equal(full, O.expected_records(iq, BB, dtype=A.RECORD_DTYPE))
 
 
+def test_pipelined_loop_with_a_resubmit_beside_every_copy_delivers_each_steps_own_records(native_libs):
+    """The loop bench.py runs, on inputs that differ from step to step: two scans on the stream at any time, a step's ordering pass in front of
+    the scan kernel after it (gather1090.hip.h), its count stored by the pass's last finisher, its packed records copied while the slot's NEXT scan
+    is already submitted (adsb_amd_scan_1090_fetch_packed_begin / _end).  Every step's records must be that step's own -- a copy that started before
+    the pass had finished, or a pass that wrote into an array still being copied, shows as records of another input -- and equal to what the same
+    scanner delivers for the same input on its own (serial submit / fetch: the stand-alone pass), which the other tests hold against the oracle.
+    Sizes: 1 024 buffers (256 MiB, 128 blocks of the ordering pass) and 40 buffers (a pass of 5 blocks inside a kernel of 1 280 waves)."""
+    import torch
+    for nbuf, steps in ((1024, 9), (40, 7)):
+        sc = A.Scanner()
+        sc.set_outputs(A.OUT_PACKED)
+        st = torch.cuda.current_stream().cuda_stream
+        inputs, want = [], []
+        for k in range(3):
+            iq, _ = synth.fill_range(7000 + k * nbuf, nbuf, nthreads=16)
+            d = torch.from_numpy(iq).cuda()
+            inputs.append(d)
+            sc.submit(d.data_ptr(), d.numel(), BB, st, 0)
+            want.append(sc.fetch_packed(0, copy=True))
+        assert len({len(w) for w in want}) == 3  # (the three inputs hold different numbers of records: a mix-up cannot pass by count)
+        got = []
+        sc.submit(inputs[0].data_ptr(), inputs[0].numel(), BB, st, 0)
+        sc.submit(inputs[1].data_ptr(), inputs[1].numel(), BB, st, 1)
+        for i in range(steps):
+            n = sc.fetch_packed_begin(i & 1)
+            if i + 2 < steps:
+                d = inputs[(i + 2) % 3]
+                sc.submit(d.data_ptr(), d.numel(), BB, st, i & 1)
+            rec = sc.fetch_packed_end(i & 1, copy=True)
+            assert len(rec) == n
+            got.append(rec)
+        for i, rec in enumerate(got):
+            w = want[i % 3]
+            assert len(rec) == len(w) and rec.tobytes() == w.tobytes(), "step %d of the pipelined loop (%d buffers) differs from the same input scanned on its own" % (i, nbuf)
+        sc.close()
+
+
 @pytest.mark.parametrize("seed", range(5))
 def test_fuzzed_threshold_cases(scanner, seed):
     """Buffers built to sit on the slicer's thresholds: samples from a small alphabet (many exact ties), frames whose pulse
@@ -514,8 +551,7 @@ def test_sharded_step_with_a_world_of_one_over_rccl(native_libs):
     """bench.py's N > 1 step (scan, hand-over of the packed records through node-shared page-locked memory with its credits, the step's
     header through the control page) run once with one rank over RCCL: the rank is seen through the control page and by the collective
     backend, and both record transports deliver the same records.  What the sharded step costs beside the plain one
-    (`sharded_over_plain`, 0.989 in profiles/r04_sharded_world_of_one.txt) is a figure of the bench line, not of this suite: boxes and
-    contexts differ by more than the few per cent it would have to resolve."""
+    (`sharded_over_plain`, 0.989 in profiles/r04_sharded_world_of_one.txt) is a figure of the bench line; the suite only holds it above 0.90."""
     import json
     import os
     import sys
@@ -525,7 +561,9 @@ def test_sharded_step_with_a_world_of_one_over_rccl(native_libs):
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["ranks_seen"] == 1 and line["rccl_ranks_seen"] == 1 and line["record_transports_agree"] in (True, None)
-    assert line["sharded_over_plain"] is not None and line["sharded_over_plain"] > 0  # reported, not gated
+    # a loose gate (round 4 measured 0.989, profiles/r04_sharded_world_of_one.txt; boxes and contexts differ by a few per cent): a collective or a
+    # wait put back into the per-step path costs tens of per cent and fails here
+    assert line["sharded_over_plain"] is not None and line["sharded_over_plain"] >= 0.90, line["sharded_over_plain"]
 
 
 def test_device_field_decoder_equals_the_host_build(scanner):
