@@ -284,17 +284,18 @@ def make_runner(args, sc, d_iq, BB, stream):
             rec = took(sc.fetch_packed((steps - 1) & 1, copy=False))
             note((steps - 1) & 1)
             return rec, acc[0], acc[1], acc[2]
-        # Two scans on the stream at any time.  A step's records: wait for its count (its ordering pass rides in front of the scan kernel after it),
-        # start the copy, submit the slot's NEXT scan beside the copy (a scan writes the slot's raw regions only), then wait for the copy.
-        sc.submit(ptr(), nbytes, BB, stream, 0)
-        if steps > 1:
-            sc.submit(ptr(), nbytes, BB, stream, 1)
+        # `depth` scans on the stream at any time.  A step's ordering pass rides in front of the scan kernel after it (gather1090.hip.h), so its count
+        # reaches the host some tens of microseconds into that kernel.  A step's records: wait for its count, start the copy, submit the slot's next
+        # scan beside the copy (a scan writes the slot's raw regions only), then wait for the copy.
+        depth = int(os.environ.get("ADSB_BENCH_DEPTH", "2"))
+        for k in range(min(depth, steps)):
+            sc.submit(ptr(), nbytes, BB, stream, k)
         for i in range(steps):
-            sc.fetch_packed_begin(i & 1)
-            note(i & 1)
-            if i + 2 < steps:
-                sc.submit(ptr(), nbytes, BB, stream, i & 1)
-            rec = took(sc.fetch_packed_end(i & 1, copy=False))
+            sc.fetch_packed_begin(i % depth)
+            note(i % depth)
+            if i + depth < steps:
+                sc.submit(ptr(), nbytes, BB, stream, i % depth)
+            rec = took(sc.fetch_packed_end(i % depth, copy=False))
         return rec, acc[0], acc[1], acc[2]
     run.delivered = made
     return run

@@ -162,11 +162,13 @@ int adsb_amd_scan_1090(adsb_amd_ctx_t* ctx, const uint8_t* iq_host, size_t nbyte
 
 /*
  * Asynchronous scan of device-resident input (no counterpart in the reference, whose HandleData is synchronous; this is the
- * recorded-file / batch form of the same DetectModeS work, ADSB1090.cpp:741-881 + :277-332).  `slot` (0/1) selects one of two result buffers so
- * that the device->host copy of one scan overlaps the kernels of the next.  `iq_device` must be
+ * recorded-file / batch form of the same DetectModeS work, ADSB1090.cpp:741-881 + :277-332).  `slot` (0 .. ADSB_AMD_SLOTS - 1) selects one of the
+ * context's result buffers so that the device->host copy of one scan overlaps the kernels of the next (two slots do; a third lets a loop keep
+ * three scans on the stream; a slot's device arrays are made when it is first used).  `iq_device` must be
  * 16-byte aligned and stay valid until the matching fetch.  `hip_stream` is a hipStream_t
  * (NULL: the context's own stream).
  */
+#define ADSB_AMD_SLOTS 3
 int adsb_amd_scan_1090_submit(adsb_amd_ctx_t* ctx, const void* iq_device, size_t nbytes, size_t buffer_bytes,
                               void* hip_stream, int slot);
 /* Waits for the slot; *records points into context-owned pinned memory, valid until the next submit on that slot. */

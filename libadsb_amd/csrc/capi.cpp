@@ -67,6 +67,7 @@ struct Slot
     bool               copying = false;  // adsb_amd_scan_1090_fetch_packed_begin has put the slot's records on the copy stream; _end has not been called
     size_t             copy_n  = 0;      // their number
     uint32_t*          next_sums = nullptr; // the sum array this scan's ordering pass zeroes (the slot's other one)
+    unsigned long long submit_no = 0;       // adsb_amd_ctx::submit_no when this scan was enqueued
     bool               events = false;     // this scan has the two timing events around its kernel
     // the submitted job (needed again when a chunk region overflows and the scan is repeated with a larger cap)
     ScanArgs    args{};
@@ -76,6 +77,9 @@ struct Slot
     float       scan_ms = 0.f, total_ms = 0.f;
 };
 } // namespace
+
+constexpr int kSlots = 3; // result slots of a context (adsb_amd.h: ADSB_AMD_SLOTS)
+static_assert(kSlots == ADSB_AMD_SLOTS, "adsb_amd.h");
 
 struct adsb_amd_ctx
 {
@@ -87,7 +91,8 @@ struct adsb_amd_ctx
     uint16_t*   lut978  = nullptr;
     uint8_t*    staging = nullptr; // device copy of host input
     size_t      staging_cap = 0;
-    Slot        slot[2];
+    Slot        slot[kSlots];
+    unsigned long long submit_no = 0;     // submits so far (a slot notes its own: the oldest scan waiting for its ordering pass is the one a new scan kernel takes on)
     unsigned    outputs = ADSB_AMD_OUT_RECORDS | ADSB_AMD_OUT_DECODED; // arrays the ordering pass produces (adsb_amd_set_outputs)
     unsigned    timing_every = 1, submits = 0; // adsb_amd_set_timing
     unsigned long long* stamps_d = nullptr; // measurement builds (diag.hip.h): four clock values per wave and launch, a ring of kStampSteps launches
@@ -257,11 +262,16 @@ int enqueue(adsb_amd_ctx* c, Slot& s)
     s.events = c->timing_every != 0 && (c->submits++ % c->timing_every) == 0;
     // the two timing events ride on the kernel's dispatch (scan1090.h); an empty input launches nothing and is not timed
     s.events = s.events && s.args.total_chunks != 0;
-    // The other slot's scan, if it is still waiting for its ordering pass on this very stream: this kernel's waves do that first (round 6).
-    Slot&             o      = c->slot[&s == &c->slot[0] ? 1 : 0];
-    const bool        attach = o.pending && !o.gather_launched && o.stream == s.stream && o.args.total_chunks != 0 && s.args.total_chunks != 0;
+    // The oldest scan of another slot that is still waiting for its ordering pass on this very stream: this kernel's waves do that pass, in front of
+    // their own work (round 6).
+    Slot* op = nullptr;
+    for (Slot& x : c->slot)
+        if (&x != &s && x.pending && !x.gather_launched && x.stream == s.stream && x.args.total_chunks != 0 && (!op || x.submit_no < op->submit_no)) op = &x;
+    const bool        attach = op != nullptr && s.args.total_chunks != 0;
+    Slot&             o      = attach ? *op : s;
     const GatherArgs  ga     = attach ? gather_args(o) : GatherArgs{};
     const GatherArgs* gp     = attach ? &ga : nullptr;
+    s.submit_no              = ++c->submit_no;
     if (c->mode == ADSB_AMD_MODE_2400) HIP_TRY(c, launch_scan2400(s.args, s.total_d, s.stream, s.events ? s.ev_scan0 : nullptr, s.events ? s.ev_scan1 : nullptr, gp));
     else HIP_TRY(c, launch_scan1090(s.args, s.total_d, s.stream, s.events ? s.ev_scan0 : nullptr, s.events ? s.ev_scan1 : nullptr, gp));
     if (attach) o.gather_launched = o.gather_attached = true;
@@ -456,7 +466,7 @@ extern "C" int adsb_amd_scan_1090_submit(adsb_amd_ctx_t* c, const void* iq_devic
                                          int slot)
 {
     if (!c) return ADSB_AMD_EINVAL;
-    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    if (slot < 0 || slot >= kSlots) return fail(c, ADSB_AMD_EINVAL, "slot must be 0, 1 or 2");
     Slot& s = c->slot[slot];
     if (s.pending) return fail(c, ADSB_AMD_ESTATE, "slot still has an unfetched scan");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -624,7 +634,7 @@ extern "C" int adsb_amd_set_timing(adsb_amd_ctx_t* c, unsigned every)
 extern "C" int adsb_amd_scan_1090_fetch_packed(adsb_amd_ctx_t* c, int slot, const adsb_amd_packed_t** packed, size_t* n)
 {
     if (!c) return ADSB_AMD_EINVAL;
-    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    if (slot < 0 || slot >= kSlots) return fail(c, ADSB_AMD_EINVAL, "slot must be 0, 1 or 2");
     Slot& s = c->slot[slot];
     if (!s.pending) return fail(c, ADSB_AMD_ESTATE, "fetch without submit");
     const int rc = fetch_slot(c, s, ADSB_AMD_OUT_PACKED);
@@ -644,7 +654,7 @@ extern "C" int adsb_amd_scan_1090_fetch_packed(adsb_amd_ctx_t* c, int slot, cons
 extern "C" int adsb_amd_scan_1090_fetch_packed_begin(adsb_amd_ctx_t* c, int slot, size_t* n)
 {
     if (!c) return ADSB_AMD_EINVAL;
-    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    if (slot < 0 || slot >= kSlots) return fail(c, ADSB_AMD_EINVAL, "slot must be 0, 1 or 2");
     Slot& s = c->slot[slot];
     if (!s.pending) return fail(c, ADSB_AMD_ESTATE, "fetch without submit");
     if (s.copying) return fail(c, ADSB_AMD_ESTATE, "the slot's last fetch has been begun and not ended");
@@ -668,7 +678,7 @@ extern "C" int adsb_amd_scan_1090_fetch_packed_begin(adsb_amd_ctx_t* c, int slot
 extern "C" int adsb_amd_scan_1090_fetch_packed_end(adsb_amd_ctx_t* c, int slot, const adsb_amd_packed_t** packed, size_t* n)
 {
     if (!c) return ADSB_AMD_EINVAL;
-    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    if (slot < 0 || slot >= kSlots) return fail(c, ADSB_AMD_EINVAL, "slot must be 0, 1 or 2");
     Slot& s = c->slot[slot];
     if (!s.copying) return fail(c, ADSB_AMD_ESTATE, "no fetch begun on this slot");
     s.copying = false;
@@ -684,7 +694,7 @@ extern "C" int adsb_amd_scan_1090_fetch_packed_end(adsb_amd_ctx_t* c, int slot, 
 extern "C" int adsb_amd_scan_1090_fetch(adsb_amd_ctx_t* c, int slot, const adsb_amd_record_t** records, size_t* n)
 {
     if (!c) return ADSB_AMD_EINVAL;
-    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    if (slot < 0 || slot >= kSlots) return fail(c, ADSB_AMD_EINVAL, "slot must be 0, 1 or 2");
     Slot& s = c->slot[slot];
     if (!s.pending) return fail(c, ADSB_AMD_ESTATE, "fetch without submit");
     const int rc = fetch_slot(c, s, ADSB_AMD_OUT_RECORDS);
@@ -699,7 +709,7 @@ extern "C" int adsb_amd_scan_1090_fetch_decoded(adsb_amd_ctx_t* c, int slot, con
                                                 size_t* n)
 {
     if (!c) return ADSB_AMD_EINVAL;
-    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    if (slot < 0 || slot >= kSlots) return fail(c, ADSB_AMD_EINVAL, "slot must be 0, 1 or 2");
     Slot& s = c->slot[slot];
     if (!s.pending) return fail(c, ADSB_AMD_ESTATE, "fetch without submit");
     const int rc = fetch_slot(c, s, ADSB_AMD_OUT_RECORDS | ADSB_AMD_OUT_DECODED);
@@ -732,7 +742,7 @@ namespace
 int fetch_device_impl(adsb_amd_ctx_t* c, int slot, void* dst_device, size_t cap, void* hip_stream, size_t* n, bool packed)
 {
     if (!c) return ADSB_AMD_EINVAL;
-    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    if (slot < 0 || slot >= kSlots) return fail(c, ADSB_AMD_EINVAL, "slot must be 0, 1 or 2");
     Slot& s = c->slot[slot];
     if (!s.pending) return fail(c, ADSB_AMD_ESTATE, "fetch without submit");
     auto body = [&]() -> int {
@@ -767,7 +777,7 @@ int fetch_device_impl(adsb_amd_ctx_t* c, int slot, void* dst_device, size_t cap,
 extern "C" int adsb_amd_scan_1090_timing(adsb_amd_ctx_t* c, int slot, float* scan_kernel_ms, float* total_ms)
 {
     if (!c) return ADSB_AMD_EINVAL;
-    if (slot < 0 || slot > 1) return fail(c, ADSB_AMD_EINVAL, "slot must be 0 or 1");
+    if (slot < 0 || slot >= kSlots) return fail(c, ADSB_AMD_EINVAL, "slot must be 0, 1 or 2");
     Slot& s = c->slot[slot];
     if (!s.timed) return fail(c, ADSB_AMD_ESTATE, "no completed, timed scan on this slot (adsb_amd_set_timing)");
     if (scan_kernel_ms) *scan_kernel_ms = s.scan_ms;

@@ -105,7 +105,6 @@ __device__ __forceinline__ void store16_through(void* p, uint4 v)
 // Every wave that takes part has its units by index (u = wave, wave + waves, ...: no counter to draw from) and works out its block's prefix for
 // itself.  Inside a scan kernel a unit is a whole block (split 1: five dependent trips of 64 records for a quiet band, ~40 us for the one wave in
 // four that does it, beside three that scan); the stand-alone pass, where nothing else runs, cuts a block into four.
-constexpr uint32_t kGatherBatch = 1; // trips of 64 records a wave keeps in flight (2: 128 vector registers and spills in the scan kernels)
 
 // One unit of the ordering pass, by one wave.  Uniform control flow; every lane must call.  Returns the records the unit moved.
 __device__ __forceinline__ uint32_t gather_unit(const GatherArgs& ga, uint32_t B, uint32_t q, uint32_t kGatherSplit, GatherLds& lds, uint32_t lane)
@@ -140,152 +139,160 @@ __device__ __forceinline__ uint32_t gather_unit(const GatherArgs& ga, uint32_t B
     }
     wave_lds_fence();
 
-    uint32_t moved = 0;
-    for (uint32_t trip0 = q * 64u; trip0 < tot; trip0 += kGatherSplit * kGatherBatch * 64u)
+    // A trip: this lane's record of 64 consecutive ones and the keys of its chunk's first four records.  The loads of the NEXT trip are issued before
+    // the current one is worked on (one trip ahead: sixteen registers), so that a block is not five times "records in, records out" one after the other.
+    struct Trip
     {
-        // ---- in: this lane's records of kGatherBatch trips and the keys of their chunks' first four records, all loads issued before any is used
-        bool         valid[kGatherBatch];
-        uint32_t     first[kGatherBatch], nn[kGatherBatch], idx[kGatherBatch], ch[kGatherBatch];
-        const uint4* src[kGatherBatch];
-        uint4        lo[kGatherBatch], hi[kGatherBatch];
-        uint2        key4[kGatherBatch][4];
+        bool         valid;
+        uint32_t     first, nn, idx, ch;
+        const uint4* src;
+        uint4        lo, hi;
+        uint2        key4[4];
+    };
+    auto fetch = [&](uint32_t trip0) -> Trip
+    {
+        Trip           t;
+        const uint32_t r = trip0 + lane; // this lane's record among the block's
+        t.valid          = r < tot;
+        // its chunk: the last one whose first record is not behind r (chunks without records share their successor's first record)
+        uint32_t cc = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < kGatherBatch; k++)
+        for (uint32_t step = kOrderChunks / 2; step >= 1; step >>= 1)
+            if (lds.cstart[cc + step] <= (t.valid ? r : 0u)) cc += step;
+        t.first = lds.cstart[cc], t.nn = lds.cstart[cc + 1] - t.first, t.idx = t.valid ? r - t.first : 0u;
+        t.ch    = B * kOrderChunks + cc;
+        t.src   = reinterpret_cast<const uint4*>(ga.chunk_records + (uint64_t)t.ch * ga.cap);
+        t.lo = t.hi = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) t.key4[j] = make_uint2(0, 0);
+        if (t.valid)
         {
-            const uint32_t r = trip0 + k * kGatherSplit * 64u + lane; // this lane's record among the block's
-            valid[k]         = r < tot;
-            // its chunk: the last one whose first record is not behind r (chunks without records share their successor's first record)
-            uint32_t cc = 0;
+            t.lo = t.src[2 * t.idx], t.hi = t.src[2 * t.idx + 1];
 #pragma unroll
-            for (uint32_t step = kOrderChunks / 2; step >= 1; step >>= 1)
-                if (lds.cstart[cc + step] <= (valid[k] ? r : 0u)) cc += step;
-            first[k] = lds.cstart[cc], nn[k] = lds.cstart[cc + 1] - first[k], idx[k] = valid[k] ? r - first[k] : 0u;
-            ch[k]    = B * kOrderChunks + cc;
-            src[k]   = reinterpret_cast<const uint4*>(ga.chunk_records + (uint64_t)ch[k] * ga.cap);
+            for (uint32_t j = 0; j < 4; j++) t.key4[j] = *reinterpret_cast<const uint2*>(&t.src[2 * (j < t.nn ? j : t.idx)]);
         }
+        return t;
+    };
+    uint32_t       moved  = 0;
+    const uint32_t stride = kGatherSplit * 64u;
+    Trip           cur    = fetch(q * 64u);
+    for (uint32_t trip0 = q * 64u; trip0 < tot; trip0 += stride)
+    {
+        Trip nxt = cur;
+        if (trip0 + stride < tot) nxt = fetch(trip0 + stride); // (uniform)
+        if (cur.valid)
+        {
+            // rank among the chunk's records by (offset, pass): their keys four at a time (a chunk seldom has more)
+            const uint32_t key  = (cur.lo.x << 1) | ((cur.lo.y >> 16) & 1u);
+            uint32_t       rank = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < kGatherBatch; k++)
-            if (valid[k])
+            for (uint32_t j = 0; j < 4; j++) rank += (((cur.key4[j].x << 1) | ((cur.key4[j].y >> 16) & 1u)) < key) ? 1u : 0u;
+            for (uint32_t k0 = 4; k0 < cur.nn; k0 += 4)
             {
-                lo[k] = src[k][2 * idx[k]], hi[k] = src[k][2 * idx[k] + 1];
+                uint2 w[4];
 #pragma unroll
-                for (uint32_t j = 0; j < 4; j++) key4[k][j] = *reinterpret_cast<const uint2*>(&src[k][2 * (j < nn[k] ? j : idx[k])]);
+                for (uint32_t j = 0; j < 4; j++) w[j] = *reinterpret_cast<const uint2*>(&cur.src[2 * (k0 + j < cur.nn ? k0 + j : cur.idx)]);
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) rank += (((w[j].x << 1) | ((w[j].y >> 16) & 1u)) < key) ? 1u : 0u;
             }
-        // ---- out
-#pragma unroll
-        for (uint32_t k = 0; k < kGatherBatch; k++)
-            if (valid[k])
+            const uint32_t buffer = cur.ch / ga.chunks_per_buf;
+            const size_t   out    = (size_t)base + cur.first + rank;
+            // raw -> adsb_amd_record_t: apply the 1-bit repair, order the bytes, pull the address out
+            const uint32_t df = cur.lo.y & 0xFFu, nbits = (cur.lo.y >> 8) & 0xFFu, flags = (cur.lo.y >> 16) & 0xFFu;
+            const int      errorbit = (int)(cur.lo.y >> 24) - 1;
+            uint4          h = cur.hi;
+            if (errorbit >= 0)
             {
-                // rank among the chunk's records by (offset, pass): their keys four at a time (a chunk seldom has more)
-                const uint32_t key  = (lo[k].x << 1) | ((lo[k].y >> 16) & 1u);
-                uint32_t       rank = 0;
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) rank += (((key4[k][j].x << 1) | ((key4[k][j].y >> 16) & 1u)) < key) ? 1u : 0u;
-                for (uint32_t k0 = 4; k0 < nn[k]; k0 += 4)
-                {
-                    uint2 w[4];
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) w[j] = *reinterpret_cast<const uint2*>(&src[k][2 * (k0 + j < nn[k] ? k0 + j : idx[k])]);
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) rank += (((w[j].x << 1) | ((w[j].y >> 16) & 1u)) < key) ? 1u : 0u;
-                }
-                const uint32_t buffer = ch[k] / ga.chunks_per_buf;
-                const size_t   out    = (size_t)base + first[k] + rank;
-                // raw -> adsb_amd_record_t: apply the 1-bit repair, order the bytes, pull the address out
-                const uint32_t df = lo[k].y & 0xFFu, nbits = (lo[k].y >> 8) & 0xFFu, flags = (lo[k].y >> 16) & 0xFFu;
-                const int      errorbit = (int)(lo[k].y >> 24) - 1;
-                uint4          h = hi[k];
-                if (errorbit >= 0)
-                {
-                    const uint32_t m = 1u << (errorbit & 31);
-                    if (errorbit < 32) h.x ^= m;
-                    else if (errorbit < 64) h.y ^= m;
-                    else if (errorbit < 96) h.z ^= m;
-                    else h.w ^= m;
-                }
-                // the message as big-endian words (first bit on top) and as bytes in memory order
-                const uint32_t B0 = __builtin_bitreverse32(h.x), B1 = __builtin_bitreverse32(h.y), B2 = __builtin_bitreverse32(h.z), B3 = __builtin_bitreverse32(h.w);
-                const uint32_t m0 = __builtin_bswap32(B0), m1 = __builtin_bswap32(B1), m2 = __builtin_bswap32(B2), m3 = __builtin_bswap32(B3); // bytes 0-3, 4-7, 8-11, 12-13
-                const uint32_t addr = (flags & ADSB_AMD_F_NEEDS_ICAO) ? lo[k].z : (B0 & 0xFFFFFFu);
-                uint4 o0;
-                o0.x = buffer;
-                o0.y = lo[k].x;
-                o0.z = addr;
-                o0.w = (lo[k].w & 0xFFFFu) | (nbits << 16) | (((uint32_t)errorbit & 0xFFu) << 24);
-                if (ga.dense)
-                {
-                    uint4* o = reinterpret_cast<uint4*>(ga.dense + out);
-                    store16_through(o, o0);
-                    store16_through(o + 1, make_uint4(df | (flags << 8) | (m0 << 16), (m0 >> 16) | (m1 << 16), (m1 >> 16) | (m2 << 16), (m2 >> 16) | (m3 << 16)));
-                }
-                // the stateless half of DecodeModesMessage, so that the host's sequential pass decodes nothing
-                const FieldsDev d = decode_fields_dev(B0, B1, B2, df, lds.ais);
-                if (ga.decoded) store16_through(ga.decoded + out, make_uint4(d.head, d.altitude, d.a, d.b));
-                if (ga.packed)
-                { // the record's first sixteen bytes, then df, flags, kind, odd and the decoded values (adsb_amd_packed_t)
-                    uint4* o = reinterpret_cast<uint4*>(ga.packed + out);
-                    store16_through(o, o0);
-                    store16_through(o + 1, make_uint4(df | (flags << 8) | ((d.head & 0xFFu) << 16) | (d.head & 0xFF000000u), d.altitude, d.a, d.b));
-                }
-                moved++;
+                const uint32_t m = 1u << (errorbit & 31);
+                if (errorbit < 32) h.x ^= m;
+                else if (errorbit < 64) h.y ^= m;
+                else if (errorbit < 96) h.z ^= m;
+                else h.w ^= m;
             }
+            // the message as big-endian words (first bit on top) and as bytes in memory order
+            const uint32_t B0 = __builtin_bitreverse32(h.x), B1 = __builtin_bitreverse32(h.y), B2 = __builtin_bitreverse32(h.z), B3 = __builtin_bitreverse32(h.w);
+            const uint32_t m0 = __builtin_bswap32(B0), m1 = __builtin_bswap32(B1), m2 = __builtin_bswap32(B2), m3 = __builtin_bswap32(B3); // bytes 0-3, 4-7, 8-11, 12-13
+            const uint32_t addr = (flags & ADSB_AMD_F_NEEDS_ICAO) ? cur.lo.z : (B0 & 0xFFFFFFu);
+            uint4 o0;
+            o0.x = buffer;
+            o0.y = cur.lo.x;
+            o0.z = addr;
+            o0.w = (cur.lo.w & 0xFFFFu) | (nbits << 16) | (((uint32_t)errorbit & 0xFFu) << 24);
+            if (ga.dense)
+            {
+                uint4* o = reinterpret_cast<uint4*>(ga.dense + out);
+                store16_through(o, o0);
+                store16_through(o + 1, make_uint4(df | (flags << 8) | (m0 << 16), (m0 >> 16) | (m1 << 16), (m1 >> 16) | (m2 << 16), (m2 >> 16) | (m3 << 16)));
+            }
+            // the stateless half of DecodeModesMessage, so that the host's sequential pass decodes nothing
+            const FieldsDev d = decode_fields_dev(B0, B1, B2, df, lds.ais);
+            if (ga.decoded) store16_through(ga.decoded + out, make_uint4(d.head, d.altitude, d.a, d.b));
+            if (ga.packed)
+            { // the record's first sixteen bytes, then df, flags, kind, odd and the decoded values (adsb_amd_packed_t)
+                uint4* o = reinterpret_cast<uint4*>(ga.packed + out);
+                store16_through(o, o0);
+                store16_through(o + 1, make_uint4(df | (flags << 8) | ((d.head & 0xFFu) << 16) | (d.head & 0xFF000000u), d.altitude, d.a, d.b));
+            }
+            moved++;
+        }
+        cur = nxt;
     }
     wave_lds_fence(); // (the next unit's prefix overwrites cstart)
     return wave_sum(moved);
 }
 
-// The units of a pass this wave takes (`wave` of `waves` take part), and what follows them: housekeeping for the slot's next scan, the wait for the
-// stores' acknowledgements, the tickets.  State words (GatherArgs::state, zeroed by the slot's scan kernel): the master word at [0..1] -- records |
-// shards finished << 32 --, the overflow flag at [2], and kGatherShards shard words, each on a line of its own, at [kStateShard0 + 32 s ..] --
-// records | units finished << 32.  A unit's ticket goes to shard u % kGatherShards (4 096 tickets on ONE word would queue for 30 us behind each
-// other); the wave that finishes a shard adds the shard's records and a ticket to the master word; the wave that finishes the last shard is the
-// pass's LAST FINISHER and tells the host.
-__device__ __forceinline__ void gather_units(const GatherArgs& ga, uint32_t wave, uint32_t waves, uint32_t kGatherSplit, GatherLds& lds, uint32_t lane)
+// A unit and what follows it: a share of the housekeeping for the slot's next scan, the wait for the stores' acknowledgements, the tickets.
+// State words (GatherArgs::state, zeroed by the slot's scan kernel): the master word at [0..1] -- records | shards finished << 32 --, the overflow
+// flag at [2], and kGatherShards shard words, each on a line of its own, at
+// [kStateShard0 + 32 s ..] -- records | units finished << 32.  A unit's ticket goes to shard u % kGatherShards (4 096 tickets on ONE word would
+// queue for 30 us behind each other); the wave that finishes a shard adds the shard's records and a ticket to the master word; the wave that
+// finishes the last shard is the pass's LAST FINISHER and tells the host.
+__device__ __forceinline__ void gather_unit_and_ticket(const GatherArgs& ga, uint32_t u, uint32_t units, uint32_t split, GatherLds& lds, uint32_t lane)
 {
-    const uint32_t units = ga.nblocks * kGatherSplit;
-    if (wave >= units) return;
-    __builtin_amdgcn_s_setprio(2); // short dependent chains beside scanning waves' dense phases (as the scan kernels' own sparse phases)
-    // housekeeping, spread over the waves that take part: the slot's other sum array (all of it: the next input may be larger) and its work counters
+    // housekeeping, spread over the units: the slot's other sum array (all of it: the next input may be larger) and its work counters start from zero
+    for (uint32_t k = u * 64u + lane; k < 2u * ga.next_entries; k += units * 64u) ga.next_block_sums[(k >> 1) * kSumStride + (k & 1u)] = 0;
+    if (u == 0)
+        for (uint32_t k = lane; k < kWorkCounters; k += 64u) ga.work_counters[k * kCounterStride] = 0;
+    const uint32_t B = u / split, q = u % split;
+    const uint32_t moved = gather_unit(ga, B, q, split, lds, lane);
+    const bool     over  = q == 0 && ga.block_sums[B * kSumStride + 1] != 0; // some chunk of this block overflowed its region
+    // Everything this wave stored has been acknowledged -- the records by memory, the zeroes by the L2 -- before its ticket counts.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t last_total = 0xFFFFFFFFu; // lane 0 of the pass's last finisher: the pass's record count
+    bool     any_over   = false;
+    if (lane == 0)
     {
-        const uint32_t nw = units < waves ? units : waves;
-        for (uint32_t k = wave * 64u + lane; k < 2u * ga.next_entries; k += nw * 64u) ga.next_block_sums[(k >> 1) * kSumStride + (k & 1u)] = 0;
-        if (wave == 0)
-            for (uint32_t k = lane; k < kWorkCounters; k += 64u) ga.work_counters[k * kCounterStride] = 0;
-    }
-    for (uint32_t u = wave; u < units; u += waves)
-    {
-        const uint32_t B = u / kGatherSplit, q = u % kGatherSplit;
-        const uint32_t moved = gather_unit(ga, B, q, kGatherSplit, lds, lane);
-        const bool     over  = q == 0 && ga.block_sums[B * kSumStride + 1] != 0; // some chunk of this block overflowed its region
-        // Everything this wave stored has been acknowledged -- the records by memory, the zeroes by the L2 -- before its ticket counts.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t last_total = 0xFFFFFFFFu; // lane 0 of the pass's last finisher: the pass's record count
-        bool     any_over   = false;
-        if (lane == 0)
+        if (over)
+        { // (a returning atomic whose value is waited for: performed before the ticket below is drawn)
+            const uint32_t was = atomicOr(&ga.state[2], 1u);
+            asm volatile("" ::"v"(was));
+        }
+        const uint32_t            shard   = u % kGatherShards, nshards = units < kGatherShards ? units : kGatherShards;
+        const uint32_t            in_shard = (units - shard + kGatherShards - 1u) / kGatherShards; // units u' < units with u' % kGatherShards == shard
+        unsigned long long* const sw = reinterpret_cast<unsigned long long*>(ga.state + kStateShard0 + 32u * shard);
+        const unsigned long long  was = atomicAdd(sw, (1ull << 32) | (unsigned long long)moved);
+        if ((uint32_t)(was >> 32) == in_shard - 1u)
         {
-            if (over)
-            { // (a returning atomic whose value is waited for: performed before the ticket below is drawn)
-                const uint32_t was = atomicOr(&ga.state[2], 1u);
-                asm volatile("" ::"v"(was));
-            }
-            const uint32_t            shard   = u % kGatherShards, nshards = units < kGatherShards ? units : kGatherShards;
-            const uint32_t            in_shard = (units - shard + kGatherShards - 1u) / kGatherShards; // units u' < units with u' % kGatherShards == shard
-            unsigned long long* const sw = reinterpret_cast<unsigned long long*>(ga.state + kStateShard0 + 32u * shard);
-            const unsigned long long  was = atomicAdd(sw, (1ull << 32) | (unsigned long long)moved);
-            if ((uint32_t)(was >> 32) == in_shard - 1u)
+            const unsigned long long m = atomicAdd(reinterpret_cast<unsigned long long*>(ga.state), (1ull << 32) | (unsigned long long)((uint32_t)was + moved));
+            if ((uint32_t)(m >> 32) == nshards - 1u)
             {
-                const unsigned long long m = atomicAdd(reinterpret_cast<unsigned long long*>(ga.state), (1ull << 32) | (unsigned long long)((uint32_t)was + moved));
-                if ((uint32_t)(m >> 32) == nshards - 1u)
-                {
-                    last_total = (uint32_t)m + (uint32_t)was + moved;
-                    any_over   = atomicOr(&ga.state[2], 0u) != 0u;
-                }
+                last_total = (uint32_t)m + (uint32_t)was + moved;
+                any_over   = atomicOr(&ga.state[2], 0u) != 0u;
             }
         }
-        if (last_total != 0xFFFFFFFFu && ga.host_word)
-            __hip_atomic_store(ga.host_word, (unsigned long long)last_total | ((unsigned long long)(((ga.stamp & 0x7FFFFFFFu) << 1) | (any_over ? 1u : 0u)) << 32),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (last_total != 0xFFFFFFFFu && ga.host_word)
+        __hip_atomic_store(ga.host_word, (unsigned long long)last_total | ((unsigned long long)(((ga.stamp & 0x7FFFFFFFu) << 1) | (any_over ? 1u : 0u)) << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The units of a pass this wave takes by index: `wave` of the `waves` that take part (no counter to draw from).
+__device__ __forceinline__ void gather_units(const GatherArgs& ga, uint32_t wave, uint32_t waves, uint32_t split, GatherLds& lds, uint32_t lane)
+{
+    const uint32_t units = ga.nblocks * split;
+    if (wave >= units) return;
+    __builtin_amdgcn_s_setprio(2); // short dependent chains beside scanning waves' dense phases (as the scan kernels' own sparse phases)
+    for (uint32_t u = wave; u < units; u += waves) gather_unit_and_ticket(ga, u, units, split, lds, lane);
     __builtin_amdgcn_s_setprio(0);
 }
 
@@ -293,7 +300,10 @@ __device__ __forceinline__ void gather_units(const GatherArgs& ga, uint32_t wave
 // waves as it has blocks, a block each -- spread over the XCDs and, as far as the order in which workgroups are placed allows to say, over the CUs: of
 // the rounds in which every CU of the chip receives a workgroup, every spacing-th, so that a SIMD has one gathering wave beside three scanning ones.
 // (Every wave gathering a quarter block first, the form before this one, cost the kernel 11 us -- as much as the separate pass had: 4 096 waves
-// waiting out the same three memory round trips with nothing else on the chip.)
+// waiting out the same three memory round trips with nothing else on the chip.  And the pass BEHIND the scan -- the waves that have run out of chunks
+// drawing quarter blocks from a counter, to fill the 20-30 us in which a launch's waves end one after the other -- made the kernel 55 us longer:
+// cut that fine the pass is 100 wave-milliseconds of waiting for memory, more than that window holds, and a unit drawn late ends 25 us after the last
+// chunk.  profiles/r06_ordering_in_kernel.txt)
 __device__ __forceinline__ void gather_in_front(const GatherArgs& ga, uint32_t ncu, GatherLds& lds, uint32_t lane)
 {
     if (ga.nblocks == 0) return;
