@@ -85,14 +85,18 @@ __device__ __forceinline__ void classify_and_emit(Emit& e, int lane, const LaneT
             // first bit (ascending) whose flip makes stored == computed
             if (nbits == 112)
             {
-                uint64_t ma = ballot(syn == lt.syn_a);
-                uint64_t mb = ballot(lane < 48 && syn == lt.syn_b);
+                int ol = lane; // (a lane number the compiler cannot see through: the two syndromes below are not hoisted out of the scan loop)
+                asm volatile("" : "+v"(ol));
+                uint64_t ma = ballot(syn == lt.crc_a);
+                uint64_t mb = ballot(ol < 48 && syn == lt.syn_b(ol));
                 if (ma) errorbit = __builtin_ctzll(ma);
                 else if (mb) errorbit = 64 + __builtin_ctzll(mb);
             }
             else
             {
-                uint64_t ms = ballot(lane < 56 && syn == lt.syn_s);
+                int ol = lane;
+                asm volatile("" : "+v"(ol));
+                uint64_t ms = ballot(ol < 56 && syn == lt.syn_s(ol));
                 if (ms) errorbit = __builtin_ctzll(ms);
             }
             if (errorbit < 0) return;
@@ -263,8 +267,10 @@ __device__ __forceinline__ int demod_strong_frame(const uint16_t* tile, uint32_t
         int errorbit = -1;
         if (syn != 0)
         { // FixSingleBitErrors (:304-332): first bit whose flip makes stored == computed
-            const uint64_t ma = is_long ? ballot(syn == lt.syn_a) : ballot(lane < 56 && syn == lt.syn_s);
-            const uint64_t mb = is_long ? ballot(lane < 48 && syn == lt.syn_b) : 0ull;
+            int ol = lane; // (a lane number the compiler cannot see through: the two syndromes are worked out here, not kept across the scan loop)
+            asm volatile("" : "+v"(ol));
+            const uint64_t ma = is_long ? ballot(syn == lt.crc_a) : ballot(ol < 56 && syn == lt.syn_s(ol));
+            const uint64_t mb = is_long ? ballot(ol < 48 && syn == lt.syn_b(ol)) : 0ull;
             if (ma) errorbit = __builtin_ctzll(ma);
             else if (mb) errorbit = 64 + __builtin_ctzll(mb);
             else return 1; // not repairable: the reference retries with phase correction
@@ -377,7 +383,8 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
             if (!need_exact)
             {
                 const uint32_t iA = (uint32_t)(fA + 0.5f), iB = (uint32_t)(fB + 0.5f);
-                const uint32_t e56 = wave_sum(lane < 56 ? iA : 0u), erest = wave_sum((lane >= 56 ? iA : 0u) + iB);
+                uint32_t e56, erest;
+                wave_sum2(lane < 56 ? iA : 0u, (lane >= 56 ? iA : 0u) + iB, e56, erest);
                 slice_resolve(lane, has_b, lane == 0 || fA >= 256.0f, valA, fB >= hi_edge, valB, &ba, &bb);
                 df    = (uint32_t)(__builtin_bitreverse64(ba) >> 59);
                 nbits = df_is_long(df) ? 112u : 56u;
@@ -392,8 +399,7 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
             x.loB = mag_of_s(sLoB); x.hiB = mag_of_s(sHiB);
             have_exact   = true;
             const int dA = abs(x.loA - x.hiA), dB = has_b ? abs(x.loB - x.hiB) : 0;
-            sum56        = wave_sum(lane < 56 ? (uint32_t)dA : 0u);
-            sumrest      = wave_sum((lane >= 56 ? (uint32_t)dA : 0u) + (uint32_t)dB);
+            wave_sum2(lane < 56 ? (uint32_t)dA : 0u, (lane >= 56 ? (uint32_t)dA : 0u) + (uint32_t)dB, sum56, sumrest);
             slice_resolve(lane, has_b, lane == 0 || dA >= 256, valA, dB >= 256, valB, &ba, &bb);
             df    = (uint32_t)(__builtin_bitreverse64(ba) >> 59);
             nbits = df_is_long(df) ? 112u : 56u;
@@ -409,8 +415,7 @@ __device__ __forceinline__ void demod_candidate(const uint16_t* tile, int lane, 
     {
         x.loB = mag_of_s(sLoB); x.hiB = mag_of_s(sHiB);
         const int dA = abs(x.loA - x.hiA), dB = has_b ? abs(x.loB - x.hiB) : 0;
-        sum56        = wave_sum(lane < 56 ? (uint32_t)dA : 0u);
-        sumrest      = wave_sum((lane >= 56 ? (uint32_t)dA : 0u) + (uint32_t)dB);
+        wave_sum2(lane < 56 ? (uint32_t)dA : 0u, (lane >= 56 ? (uint32_t)dA : 0u) + (uint32_t)dB, sum56, sumrest);
     }
     const int loA = x.loA, hiA = x.hiA, loB = x.loB, hiB = x.hiB;
 

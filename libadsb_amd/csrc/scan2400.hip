@@ -12,16 +12,17 @@
 //   * the gate (oracle2400_gate) runs in two steps since round 5.  Dense, on the MATRIX pipe: a necessary condition that is linear in s,
 //         (s0+s1) + (s2+s3) + (s8+s9) > 2 (s-1 + s5+s6+s7 + s14+s15+s16+s17)
 //     (3 min(A,B,C,D) > 2 Q implies 3 (A+B+C)/3 > 2 Q), evaluated for 1024 positions at a time as a banded (Toeplitz) matrix product with
-//     v_mfma_i32_32x32x32_i8: the image itself is the B operand -- 32 columns, column c = the 64 samples from 32 c - 8 on, read as bytes
-//     (low byte, high byte of every half) --, the A operand holds the filter's weights for the 32 positions of a column, once for the low
-//     bytes and once for the high bytes (an i8 weight cannot carry the factor 256 between them: two accumulators, combined with one
-//     shift-add).  The vector unit only combines, collects sign bits and XORs bit 7 of the low bytes (the matrix cores multiply signed
-//     bytes: low byte ^ 0x80 is low byte - 128, a constant per filter that the accumulators' initial values take out): about 4 vector
-//     instructions per 64 positions where the packed 16-bit gate took 8.3.  The survivors of that condition (about forty per chunk) go
+//     v_mfma_f32_32x32x16_f16: the image itself is the B operand -- 32 columns, column c = the 64 samples from 32 c - 8 on, converted to f16 on
+//     the way in --, the A operand holds the filter's weights for the 32 positions of a column (a 4 KB device table, fetched per chunk).  f16 x f16
+//     products are exact in f32; what is not exact (the conversion of a 15-bit s to eleven bits of mantissa, the f32 summation) is covered the safe
+//     way round: weights 1 + 2^-10 and -2 (1 - 2^-11), accumulators started at +4, so that the sign says "fail" only where the exact sum fails.
+//     The vector unit converts and collects 32 sign bits per register: 3.1 instructions per 64 positions where the packed 16-bit gate took 8.3.
+//     (The exact integer form -- v_mfma_i32_32x32x32_i8 over the low and the high bytes of the halves, two chains -- was built first and is not
+//     what runs: no faster than the packed gate, profiles/r05_mode2400_variants.txt.)  The survivors of that condition (about forty per chunk) go
 //     through the exact gate sparsely, a lane each;
-//   * a candidate is demodulated by the whole wave: first the preamble correlation of the five sub-sample phases, on registers
-//     (each row of 16 lanes holds the 13 magnitudes once, weighted for its phase, DPP row sums) -- most gate survivors of noise
-//     end there; then per phase tried lane b slices bit b and bit 64 + b from four samples with the overlap weights of its own
+//   * the preamble correlation of the five sub-sample phases for sixteen gate survivors at a time, exactly, as an i8 matrix product
+//     (v_mfma_i32_32x32x32_i8 over the bytes of the survivors' exact magnitudes: kScoreTable) -- most gate survivors of noise end there;
+//   * a candidate is demodulated by the whole wave: per phase tried lane b slices bit b and bit 64 + b from four samples with the overlap weights of its own
 //     sub-sample position -- on float estimates of the magnitudes, exactly only where a decision lies inside the estimates' error
 //     margin --, ballots give the message, parity is the DPP XOR reduction of per-lane table entries, the one-bit repair a
 //     ballot over per-lane syndromes (shared with the 2 MS/s kernel).
@@ -238,12 +239,11 @@ __device__ __forceinline__ bool slice_and_emit(const uint16_t* img16, uint32_t a
         if (syn != 0)
         {
             if (weak > 2) return false;
-            // the syndrome of flipping a bit: its parity-table entry for a data bit, the bit itself inside the parity field (load_lane_tables'
-            // syn_*; worked out here, in the one frame in ten that needs a repair, from a lane number the compiler cannot see through: as three
-            // more lane constants kept for the whole launch they cost registers the prefetched window needs)
+            // the syndromes of flipping a bit, worked out here, in the one frame in ten that needs a repair, from a lane number the compiler cannot see
+            // through (LaneTables::syn_b / syn_s, scan_common.hip.h)
             int ol = lane;
             asm volatile("" : "+v"(ol));
-            const uint32_t syn_b = ol < 24 ? lt.crc_b : 1u << ((47 - ol) & 31), syn_s = ol < 32 ? lt.crc_s : 1u << ((55 - ol) & 31);
+            const uint32_t syn_b = lt.syn_b(ol), syn_s = lt.syn_s(ol);
             const uint64_t ma = is_long ? ballot(syn == lt.crc_a) : ballot(ol < 56 && syn == syn_s);
             const uint64_t mb = is_long ? ballot(ol < 48 && syn == syn_b) : 0ull;
             if (ma) errorbit = __builtin_ctzll(ma);

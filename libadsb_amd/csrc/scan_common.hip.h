@@ -132,6 +132,32 @@ __device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t x)
     return x;
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add(v), 63); }
+// Two sums at once, the two chains interleaved step by step: a DPP operand written by the previous vector instruction needs two wait states, and the
+// other chain's step is one of them (round 6: the general demodulation path forms its two energy sums back to back)
+__device__ __forceinline__ void wave_sum2(uint32_t a, uint32_t b, uint32_t& sa, uint32_t& sb)
+{
+    asm("s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b));
+    sa = (uint32_t)__builtin_amdgcn_readlane((int)a, 63), sb = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+}
 __device__ __forceinline__ uint32_t wave_xor(uint32_t x)
 {
     x ^= dpp_or_zero<0x111, 0xF>(x);
@@ -202,12 +228,14 @@ __device__ __forceinline__ void slice_resolve(int lane, bool has_b, bool decided
 
 struct LaneTables
 {
-    uint32_t syn_a; // 112-bit message: syndrome of flipping bit `lane`
-    uint32_t syn_b; // 112-bit message: syndrome of flipping bit 64+lane (lane < 48)
-    uint32_t syn_s; // 56-bit message: syndrome of flipping bit `lane` (lane < 56)
-    uint32_t crc_a; // parity-table entry of bit `lane` (112-bit)
+    uint32_t crc_a; // parity-table entry of bit `lane` (112-bit) = the syndrome of flipping it (lane < 64 < 88: always a data bit)
     uint32_t crc_b; // parity-table entry of bit 64+lane
     uint32_t crc_s; // parity-table entry of bit `lane` of a 56-bit message
+    // The syndromes of flipping bit 64 + lane of a long message / bit `lane` of a short one -- the table entry for a data bit, the bit itself inside
+    // the parity field (FixSingleBitErrors :304-332) -- are worked out where a repair is tried, the one frame in ten (round 6; as three more lane
+    // constants kept for the whole launch they were registers the ordering pass in front of the scan and the prefetched window can use).
+    __device__ __forceinline__ uint32_t syn_b(int lane) const { return lane < 24 ? crc_b : (lane < 48 ? 1u << ((47 - lane) & 31) : 0xFFFFFFFFu); }
+    __device__ __forceinline__ uint32_t syn_s(int lane) const { return lane < 32 ? crc_s : (lane < 56 ? 1u << ((55 - lane) & 31) : 0xFFFFFFFFu); }
 };
 
 __device__ __forceinline__ LaneTables load_lane_tables(const uint32_t* __restrict__ tab, int lane)
@@ -220,11 +248,6 @@ __device__ __forceinline__ LaneTables load_lane_tables(const uint32_t* __restric
     t.crc_a     = ta;
     t.crc_b     = tb;
     t.crc_s     = ts;
-    // flipping a bit of the parity field itself changes the stored value by that bit (FixSingleBitErrors :304-332)
-    int ba = lane, bb = 64 + lane;
-    t.syn_a = ta; // lane < 64 < 88: always a data bit
-    t.syn_b = (lane < 48) ? ((bb < 88) ? tb : (1u << (111 - bb))) : 0xFFFFFFFFu;
-    t.syn_s = (lane < 56) ? ((ba < 32) ? ts : (1u << (55 - ba))) : 0xFFFFFFFFu;
     return t;
 }
 
