@@ -13,24 +13,29 @@ constexpr int kUatUplinkBytes = 552;
 constexpr int kUatUplinkBits  = kUatUplinkBytes * 8;
 constexpr uint32_t kUatDemodRanges = 64;
 
-// one per 18-bit match, in candidate order; variant v = frame taken from sample index + v.  32 bytes: what the host's scan loop reads
-// for every match.  The corrected ADS-B frame bytes live in a parallel array (kUatPayloadStride bytes per match), read only when a
-// frame is handed to a listener: the loop walks 78 000 of these per GiB, straight out of memory the GPU has just written.
+// one per 18-bit match, in candidate order; variant v = frame taken from sample index + v.  16 bytes: what the host reads for a match whose frame the
+// scan loop takes (round 6: the two register windows, which only the host's own scan loop -- the fall-back -- reads, moved to uat_win_t, a parallel
+// array that goes to the host only when that loop runs: 1.25 MB per GiB less on the host link per call).  The corrected ADS-B frame bytes live in a
+// second parallel array (kUatPayloadStride bytes per match), read only when a frame is handed to a listener.
 struct uat_rec_t
 {
     uint32_t index;       // sample index of the first sync bit
     int16_t  skip;        // bits the scan loop jumps when it takes this frame: 276 short, 420 long, 4452 uplink; 0 = no frame
     uint8_t  rs;          // corrected symbols of the frame taken (uplink: sum over the six blocks); 255 = no frame
     uint8_t  kind;        // 0 = ADS-B sync word, 1 = uplink sync word
-    uint64_t window;      // sign bits from sample 2 * (index >> 1) on, low word = even samples (register 0), high word = odd
-                          // samples (register 1), bit k = k-th bit time: both 18-bit registers at detection time
-    uint64_t after;       // the same from bit (index >> 1) + skip + 1 on: what enters the registers after the jump
     uint8_t  variant;     // the frame was taken from sample index + variant (the reference demodulates both and keeps the one
                           // with fewer corrections, the first on a tie); 2 = neither decodes
     uint8_t  pad0[3];
     uint32_t slot;        // uplink: 432-byte slot of the decoded payload in the side array
 };
-static_assert(sizeof(uat_rec_t) == 32, "record layout");
+static_assert(sizeof(uat_rec_t) == 16, "record layout");
+struct uat_win_t
+{
+    uint64_t window;      // sign bits from sample 2 * (index >> 1) on, low word = even samples (register 0), high word = odd
+                          // samples (register 1), bit k = k-th bit time: both 18-bit registers at detection time
+    uint64_t after;       // the same from bit (index >> 1) + skip + 1 on: what enters the registers after the jump
+};
+static_assert(sizeof(uat_win_t) == 16, "window layout");
 constexpr uint32_t kUatPayloadStride = 40; // ADS-B: corrected frame bytes 0..33 (18 of them for a short frame: skip == 276), 
 // The matches of a stream, binned by position while they are found (round 6): bin = sample index >> kUatBinShift, kUatBinCap slots each.
 constexpr uint32_t kUatBinShift = 15, kUatBinCap = 16;
@@ -44,7 +49,7 @@ struct uat_extra_t
     uat_rec_t rec;
     uint32_t  parent, seq, pad[2];
 };
-static_assert(sizeof(uat_extra_t) == 48, "extra record layout");
+static_assert(sizeof(uat_extra_t) == 32, "extra record layout");
 constexpr uint32_t kUatExtraCap = 4096; // per call (about 19 per GiB of frame-dense stream); past it the host walks the loop itself
 constexpr uint32_t kUatEnd      = 0xFFFFFFFFu; // successor / emit value: none
 // counts[]: what the kernels of one call report
@@ -77,6 +82,7 @@ struct UatArgs
     uint32_t*       counts; // kUatCountWords words, see UatCount
     uint32_t*       up_list; // cand_cap entries: positions of the uplink matches in the ordered list
     uat_rec_t*      recs;   // cand_cap entries
+    uat_win_t*      wins;   // parallel to recs: the register windows (for the host's own scan loop)
     uint8_t*        payloads; // cand_cap x kUatPayloadStride bytes, parallel to recs
     uint8_t*        uplink_payloads; // uplink_cap x 432 bytes
     uint32_t        uplink_cap;

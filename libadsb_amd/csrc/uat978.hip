@@ -1130,7 +1130,7 @@ constexpr size_t kCuLdsBytes = 160 * 1024;
 template <bool PHASES_GIVEN>
 __global__ __launch_bounds__(64 * kUatDemodWaves, 6) void uat_demod_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ lut, uint64_t n,
                                                        const RsTables* __restrict__ rs_tables, const uint32_t* __restrict__ cand, uint32_t ncand,
-                                                       uat_rec_t* __restrict__ recs, uint8_t* __restrict__ payloads, uint8_t* __restrict__ uplink_payloads,
+                                                       uat_rec_t* __restrict__ recs, uat_win_t* __restrict__ wins, uint8_t* __restrict__ payloads, uint8_t* __restrict__ uplink_payloads,
                                                        uint32_t uplink_cap,
                                                        uint32_t* __restrict__ uplink_count, uint32_t* __restrict__ work_counters, uint32_t nranges,
                                                        const uint32_t* __restrict__ up_list, const uint32_t* __restrict__ up_count, uint32_t single_word,
@@ -1183,6 +1183,7 @@ __global__ __launch_bounds__(64 * kUatDemodWaves, 6) void uat_demod_kernel(const
         const uint32_t c         = from_list ? up_list[range + item * nranges] : first + (item - nup_r);
         uint32_t   word = cand ? cand[c] : single_word; // cand == nullptr: one look-up the host asked for, passed by value
         uat_rec_t* r    = &recs[c];
+        uat_win_t* wn   = &wins[c]; // (null behind a frame: the frames the loop reaches through stale register bits carry no windows of their own)
         uint8_t*   pay  = payloads + (size_t)c * kUatPayloadStride;
         if (!from_list && (word >> 31) && up_list)
         { // an uplink match inside the slice: taken in the first phase
@@ -1414,8 +1415,8 @@ __global__ __launch_bounds__(64 * kUatDemodWaves, 6) void uat_demod_kernel(const
         {
             r->index = (uint32_t)idx, r->kind = (uint8_t)kind, r->variant = (uint8_t)v_take;
             r->skip = (int16_t)skip_t, r->rs = (uint8_t)(v_take < 2 ? rs_t : 255);
-            r->slot = up_slot, r->window = diag::kUatParts <= 6 ? w0 + sink : w0;
-            r->after = after;
+            r->slot = up_slot;
+            if (wn) wn->window = diag::kUatParts <= 6 ? w0 + sink : w0, wn->after = after;
         }
         wave_fence(); // raw[] is reused by the next position
         UAT_DIAG_LAP(kDiagOutput);
@@ -1463,7 +1464,7 @@ __global__ __launch_bounds__(64 * kUatDemodWaves, 6) void uat_demod_kernel(const
         }
         if (lane == 0) extras[x].parent = c, extras[x].seq = seq;
         seq++;
-        word = at | (k2 << 31), r = &extras[x].rec, pay = extra_payloads + (size_t)x * kUatPayloadStride, chained = true;
+        word = at | (k2 << 31), r = &extras[x].rec, wn = nullptr, pay = extra_payloads + (size_t)x * kUatPayloadStride, chained = true;
         }
         item = next_item;
     }
@@ -1962,11 +1963,11 @@ hipError_t launch_uat978_demod(const UatArgs& a, uint32_t ncand, bool ordered, h
     const uint32_t* up_count = ordered ? a.counts + 2 : nullptr;
     uint32_t*       chase    = ordered ? a.next_bit : nullptr; // the frames behind a frame are followed for the ordered list only
     if (a.phases_given)
-        hipLaunchKernelGGL(uat_demod_kernel<true>, dim3(g), dim3(64 * kUatDemodWaves), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
+        hipLaunchKernelGGL(uat_demod_kernel<true>, dim3(g), dim3(64 * kUatDemodWaves), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs, a.wins,
                            a.payloads, a.uplink_payloads, a.uplink_cap, a.counts + 1, work, nranges, up_list, up_count, a.single_word,
                            a.lenbits, chase, a.extras, a.extra_payloads, a.extra_cap, a.counts);
     else
-        hipLaunchKernelGGL(uat_demod_kernel<false>, dim3(g), dim3(64 * kUatDemodWaves), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs,
+        hipLaunchKernelGGL(uat_demod_kernel<false>, dim3(g), dim3(64 * kUatDemodWaves), 0, stream, a.in, a.lut, a.nsamples, a.rs_tables, a.cand, ncand, a.recs, a.wins,
                            a.payloads, a.uplink_payloads, a.uplink_cap, a.counts + 1, work, nranges, up_list, up_count, a.single_word,
                            a.lenbits, chase, a.extras, a.extra_payloads, a.extra_cap, a.counts);
     return hipGetLastError();

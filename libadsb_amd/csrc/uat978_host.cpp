@@ -174,6 +174,9 @@ struct adsb_amd_uat
     uint32_t*  demod_work_d = nullptr;
     uint32_t*  counts_h = nullptr; // pinned
     uat_rec_t* recs_d = nullptr;
+    uat_win_t* wins_d = nullptr; // parallel to recs_d: the register windows, fetched only for the host's own scan loop
+    Pinned<uat_win_t> wins_h;
+    bool       wins_on_host = false; // wins_h holds the windows of this call's first nmain records
     uint8_t*   pay_d  = nullptr; // corrected ADS-B frame bytes, kUatPayloadStride per record, parallel to recs_d
     uint8_t*   up_d = nullptr; // decoded uplink payloads, 432 bytes per slot
     uint32_t   up_cap = 0;
@@ -229,7 +232,7 @@ struct adsb_amd_uat
     {
         stop_pipeline();
         (void)hipSetDevice(device);
-        for (void* p : {(void*)lut_d, (void*)rs_d, (void*)signs_d, (void*)cand_d, (void*)sorted_d, (void*)order_scratch_d, (void*)counts_d, (void*)demod_work_d, (void*)bin_fill_d[0], (void*)bin_fill_d[1], (void*)bin_slots_d, (void*)recs_d, (void*)pay_d, (void*)up_d, (void*)in_d,
+        for (void* p : {(void*)lut_d, (void*)rs_d, (void*)signs_d, (void*)cand_d, (void*)sorted_d, (void*)order_scratch_d, (void*)counts_d, (void*)demod_work_d, (void*)bin_fill_d[0], (void*)bin_fill_d[1], (void*)bin_slots_d, (void*)recs_d, (void*)wins_d, (void*)pay_d, (void*)up_d, (void*)in_d,
                         (void*)stage_d, (void*)stage_tmp_d, (void*)next_bit_d, (void*)succ_d, (void*)exit_d, (void*)emit_d, (void*)marks_d, (void*)extras_d, (void*)extra_pay_d})
             if (p) (void)hipFree(p);
         if (counts_h) (void)hipHostFree(counts_h);
@@ -325,6 +328,8 @@ struct adsb_amd_uat
         uint32_t* old_sorted = sorted_d;
         if (cand_d) (void)hipFree(cand_d);
         if (recs_d) (void)hipFree(recs_d);
+        if (wins_d) (void)hipFree(wins_d);
+        wins_d = nullptr;
         if (pay_d) (void)hipFree(pay_d);
         for (uint32_t** p : {&next_bit_d, &succ_d, &exit_d, &emit_d, &marks_d})
         {
@@ -342,6 +347,7 @@ struct adsb_amd_uat
             (void)hipFree(old_sorted);
         }
         UAT_HIP(hipMalloc(&recs_d, (size_t)want * sizeof(uat_rec_t)));
+        UAT_HIP(hipMalloc(&wins_d, (size_t)want * sizeof(uat_win_t)));
         UAT_HIP(hipMalloc(&pay_d, (size_t)want * kUatPayloadStride));
         for (uint32_t** p : {&next_bit_d, &succ_d, &exit_d, &emit_d, &marks_d}) UAT_HIP(hipMalloc(p, (size_t)want * sizeof(uint32_t)));
         cand_cap = want;
@@ -378,7 +384,7 @@ struct adsb_amd_uat
         UatArgs a{};
         a.in = in, a.lut = lut_d, a.rs_tables = rs_d, a.nsamples = n, a.phases_given = phases_given ? 1 : 0, a.ncu = ncu;
         a.signs = signs_d, a.cand = cand_d, a.cand_cap = cand_cap, a.counts = counts_d; // demod_on_device points a.cand at sorted_d
-        a.recs = recs_d, a.payloads = pay_d, a.uplink_payloads = up_d, a.uplink_cap = up_cap, a.demod_work = demod_work_d;
+        a.recs = recs_d, a.wins = wins_d, a.payloads = pay_d, a.uplink_payloads = up_d, a.uplink_cap = up_cap, a.demod_work = demod_work_d;
         if (!phases_given) a.bin_fill = bin_fill_d[bin_phase], a.bin_fill_next = bin_fill_d[bin_phase ^ 1], a.bins_cap = bins_cap, a.bin_slots = bin_slots_d;
         a.up_list = order_scratch_d ? order_scratch_d + 2 * (size_t)((n + 32767) / 32768) + 2 : nullptr;
         a.lenbits = (int64_t)(n / 2) - (kUatSyncBits + kUatUplinkBits);
@@ -399,6 +405,7 @@ struct adsb_amd_uat
         if (!rc) rc = reserve_cand(std::max<uint32_t>(cand_cap, 4096));
         if (rc) return rc;
         nrecords = nmain = nuplink = nextras = 0;
+        wins_on_host = false;
         decided = false;
         extra.clear();
         const double t0 = now_ms();
@@ -629,11 +636,14 @@ struct adsb_amd_uat
             a.cand        = nullptr;
             a.single_word = (index & 0x7FFFFFFFu) | (kind << 31);
             a.recs += at;
+            a.wins += at;
             a.payloads += (size_t)at * kUatPayloadStride;
             UAT_HIP(recs_h.reserve((size_t)at + 1, at));
+            UAT_HIP(wins_h.reserve((size_t)at + 1, wins_on_host ? at : 0));
             UAT_HIP(pay_h.reserve(((size_t)at + 1) * kUatPayloadStride, (size_t)at * kUatPayloadStride));
             UAT_HIP(launch_uat978_demod(a, 1, false, stream));
             UAT_HIP(hipMemcpyAsync(recs_h.p + at, recs_d + at, sizeof(uat_rec_t), hipMemcpyDeviceToHost, stream));
+            UAT_HIP(hipMemcpyAsync(wins_h.p + at, wins_d + at, sizeof(uat_win_t), hipMemcpyDeviceToHost, stream));
             UAT_HIP(hipMemcpyAsync(pay_h.p + (size_t)at * kUatPayloadStride, pay_d + (size_t)at * kUatPayloadStride, kUatPayloadStride, hipMemcpyDeviceToHost, stream));
             UAT_HIP(hipStreamSynchronize(stream));
             const uat_rec_t& r = recs_h.p[at];
@@ -748,6 +758,14 @@ struct adsb_amd_uat
         int           rc      = ADSB_AMD_OK;
         const double  t_loop  = now_ms();
         const int64_t lenbits = (int64_t)(len / 2) - (kUatSyncBits + kUatUplinkBits);
+        if (!wins_on_host && nmain)
+        { // the register windows of the matches: only this loop reads them, so only now do they cross the host link
+            UAT_HIP(wins_h.reserve(std::max<size_t>(nmain, nrecords), 0));
+            UAT_HIP(hipMemcpyAsync(wins_h.p, wins_d, (size_t)nmain * sizeof(uat_win_t), hipMemcpyDeviceToHost, stream));
+            UAT_HIP(hipStreamSynchronize(stream));
+        }
+        wins_on_host = true;
+        auto win_of = [&](const uat_rec_t* r) -> const uat_win_t& { return wins_h.p[r - recs_h.p]; };
 
         int64_t bit = 0; // next bit the loop will examine
         size_t  pos = 0;
@@ -786,8 +804,8 @@ struct adsb_amd_uat
             emit(*r, a);
             // --- jump: bit = startbit + skip, then the loop's ++.  The registers keep their contents, so for the next 17 bits
             // they mix bits from before the jump with new ones and can fire where the stream itself has no match.
-            uint32_t oldw[2] = {(uint32_t)r->window & kCheckMask, (uint32_t)(r->window >> 32) & kCheckMask};
-            uint64_t fresh   = r->after;
+            uint32_t oldw[2] = {(uint32_t)win_of(r).window & kCheckMask, (uint32_t)(win_of(r).window >> 32) & kCheckMask};
+            uint64_t fresh   = win_of(r).after;
             bit              = startbit + a.skip + 1;
             for (;;)
             {
@@ -821,7 +839,7 @@ struct adsb_amd_uat
                     if (!attempt(r2, a2)) continue;
                     emit(r2, a2);
                     oldw[0] = w0, oldw[1] = w1;
-                    fresh   = r2.after;
+                    fresh   = win_of(&r2).after;
                     bit     = sb2 + a2.skip + 1;
                     jumped  = true;
                     break;
