@@ -68,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--rotate", type=int, default=1, help="N = 1: K distinct device-resident inputs of --mib each (generator buffers k * nbuf ...), step i scans "
                     "input i mod K: nothing a step reads was read by the K - 1 steps before it, so neither the L2s nor the 256 MiB memory-side cache "
                     "can serve it (K = 1, the default, rescans one resident input; profiles/r06_rotate.txt holds the A/B)")
+    ap.add_argument("--depth", type=int, default=2, help="N = 1: scans on the stream at any time in the pipelined loop (2, the default, or 3: the context has three "
+                    "result slots; measured no faster, profiles/r06_ordering_in_kernel.txt)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the end_to_end and uat978 blocks (profiling runs)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N > 1 ranks all on cuda:0 with the gloo backend: exercises the "
                     "multi-rank code path (sharding, record gather, resolve) on a one-GPU box; the numbers mean nothing")
@@ -287,7 +289,7 @@ def make_runner(args, sc, d_iq, BB, stream):
         # `depth` scans on the stream at any time.  A step's ordering pass rides in front of the scan kernel after it (gather1090.hip.h), so its count
         # reaches the host some tens of microseconds into that kernel.  A step's records: wait for its count, start the copy, submit the slot's next
         # scan beside the copy (a scan writes the slot's raw regions only), then wait for the copy.
-        depth = int(os.environ.get("ADSB_BENCH_DEPTH", "2"))
+        depth = max(1, min(3, getattr(args, "depth", 2)))
         for k in range(min(depth, steps)):
             sc.submit(ptr(), nbytes, BB, stream, k)
         for i in range(steps):
@@ -402,15 +404,17 @@ def bench_1090_single(args, local_rank, A, synth, torch):
                                 "repair; kernel == oracle/oracle2400.c in the GPU tests" % args.mib),
                    "sample_rate_x10": args.rate,
                    "bytes_per_gpu": nbytes, "buffers_per_gpu": nbuf, "sharding": "one GPU", "pipelined": not args.serial,
+                   "scans_on_the_stream": 1 if args.serial else max(1, min(3, args.depth)),
                    "rotate": {"inputs": len(rotation), "what": "step i scans device-resident input i mod K (K x %d MiB, generator buffers k * %d ...)" % (args.mib, nbuf),
                               "records_per_step_mean": round(nrec_mean, 1)} if len(rotation) > 1 else None},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(nbytes if args.rate == 20 else "mode2400:%d" % nbytes),
                      "kernel": "scan1090_kernel" if args.rate == 20 else "scan2400_kernel", "kernel_ms": round(kernel_ms, 4),
                      "kernel_ms_source": "HIP events on the kernel's dispatch (hipExtLaunchKernelGGL start/stop events, the stream the scan is launched on), "
-                                         "%d of the %d timed launches (every %s), in the pipelined loop: the copy engine moves the previous step's records "
-                                         "to the host beside the kernel, which costs it about 2-5 %% -- rocprofv3 of `bench.py --serial` (profiles/) has no "
-                                         "copy beside the kernel and reads that much lower" % (k_n, args.steps, args.time_every),
+                                         "%d of the %d timed launches (every %s), in the pipelined loop: since round 6 the kernel also does the ORDERING PASS of the "
+                                         "scan before it (a quarter of its waves, in front of their own chunks: gather1090.hip.h; ~7 us of the figure), and the copy "
+                                         "engine moves the previous step's records to the host beside it (2-5 %%) -- rocprofv3 of `bench.py --serial` (profiles/) has "
+                                         "neither in or beside the scan kernel (the pass is a launch of its own there) and reads that much lower" % (k_n, args.steps, args.time_every),
                      "kernel_ms_first_100": round(k100 / max(1, n100), 4),
                      "algorithmic_bytes": int(alg_bytes)},
         "records_per_step": nrec, "frames_injected": injected,
@@ -456,7 +460,7 @@ def bench_1090_single(args, local_rank, A, synth, torch):
                 "records_per_step": int(len(r24)), "frames_injected": int(inj24), "accepted_frames": int(acc24),
                 "transmitted_frames_recovered": recovered_2400(A, synth, local_rank),
                 "note": "PARITY UNPINNED: 1 GiB of the generator's pulse trains sampled at 2.4 MS/s through ADSB_AMD_MODE_2400 (specification "
-                        "oracle/oracle2400.c; no reference demodulator for this rate exists, SURVEY.md F3/F5); kernel by part and what is left to do: DESIGN.md section 11"}
+                        "oracle/oracle2400.c; no reference demodulator for this rate exists, SURVEY.md F3/F5); kernel by part and what is left to do: DESIGN.md section 10, profiles/r06_mode2400_variants.txt"}
             sc24.close()
             del d24, iq24
         except Exception as e:

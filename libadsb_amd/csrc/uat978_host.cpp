@@ -192,6 +192,13 @@ struct adsb_amd_uat
     bool       bins_dirty = false;   // a call ended between the match search and the ordering pass: the current fill counts are not zero
     bool       bins_ordered = false; // the last call's ordering was the one-launch form
     hipStream_t copy_stream2 = nullptr; // the frame bytes beside the records: two copy engines share the host link (46 -> ~55 GB/s)
+    // Calls in flight: the three sides' compute streams, made ONE AFTER THE OTHER when the pipeline is first used (side s runs on pipe_stream[s]).
+    // The runtime deals streams onto a handful of hardware queues in the order they are made; two sides whose streams share a queue run their kernels
+    // one after the other, not side by side (round 6: 0.43 against 0.55 ms per step with the very same kernels, by how many streams the process
+    // had made before).  Made together they land on neighbouring queues.  Twins own no stream of their own.
+    hipStream_t pipe_stream[3] = {nullptr, nullptr, nullptr};
+    hipStream_t own_stream = nullptr; // what `stream` is outside the pipeline (side 0 borrows pipe_stream[0] while it runs a submitted call)
+    bool        borrowed_stream = false; // `stream` belongs to the handle that made this twin
     hipEvent_t  ev_copy2 = nullptr;
     std::unordered_map<uint64_t, uint32_t> extra; // positions asked for on top of those: (index << 1 | kind) -> record
     uint32_t   nrecords = 0, nmain = 0, nuplink = 0;
@@ -243,20 +250,23 @@ struct adsb_amd_uat
         if (ev_demod) (void)hipEventDestroy(ev_demod);
         if (ev_counts) (void)hipEventDestroy(ev_counts);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        for (auto ps : pipe_stream)
+            if (ps) (void)hipStreamDestroy(ps);
+        if (borrowed_stream) stream = nullptr;
         if (stream) (void)hipStreamDestroy(stream);
     }
 
-    int init()
+    int init(hipStream_t use_stream = nullptr)
     {
         UAT_HIP(hipSetDevice(device));
         {
             int n = 0;
             if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) ncu = (uint32_t)n;
         }
-        UAT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        UAT_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        if (use_stream) stream = use_stream, borrowed_stream = true; // a twin: one of the handle's pipeline streams
+        else UAT_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        // (the copy streams are made when a call on its own first needs them: decide_and_fetch)
         for (auto& e : ev) UAT_HIP(hipEventCreate(&e));
-        UAT_HIP(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
         UAT_HIP(hipEventCreateWithFlags(&ev_copy2, hipEventDisableTiming));
         UAT_HIP(hipEventCreateWithFlags(&ev_demod, hipEventDisableTiming));
         UAT_HIP(hipEventCreateWithFlags(&ev_counts, hipEventDisableTiming));
@@ -540,11 +550,16 @@ struct adsb_amd_uat
             // (1) behind the demodulation pass, on the copy stream: its counts first (they say how much more there is to fetch), then the records
             // and the payloads.  The decision kernels read none of this and write none of it.
             static_assert(kUatCountUplinkSlots == 1 && kUatCountOverflow == 4 && kUatCountFinalBit == 5 && kUatCountTaken == 6, "the two copies of the counts below");
+            if (!copy_stream) UAT_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
             UAT_HIP(hipStreamWaitEvent(copy_stream, ev_demod, 0));
             UAT_HIP(hipMemcpyAsync(counts_h + kUatCountUplinkSlots, counts_d + kUatCountUplinkSlots, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, copy_stream));
             UAT_HIP(hipEventRecord(ev_counts, copy_stream));
             UAT_HIP(hipMemcpyAsync(recs_h.p, recs_d, (size_t)count * sizeof(uat_rec_t), hipMemcpyDeviceToHost, copy_stream));
-            UAT_HIP(hipStreamWaitEvent(copy_stream2, ev_demod, 0)); // (round 6) the frame bytes on a second copy stream, beside the records
+            // (round 6) the frame bytes on a second copy stream, beside the records.  Made on first use: only a handle that runs calls on its own has one
+            // -- the runtime deals streams onto a handful of hardware queues in the order they are made, and three more streams that the handle's two
+            // twins (calls in flight) never use shifted the twins' compute streams onto one queue: 0.43 -> 0.55 ms per pipelined step inside bench.py
+            if (!copy_stream2) UAT_HIP(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
+            UAT_HIP(hipStreamWaitEvent(copy_stream2, ev_demod, 0));
             UAT_HIP(hipMemcpyAsync(pay_h.p, pay_d, (size_t)count * kUatPayloadStride, hipMemcpyDeviceToHost, copy_stream2));
             UAT_HIP(hipEventRecord(ev_copy2, copy_stream2));
             if (decide)
@@ -566,7 +581,7 @@ struct adsb_amd_uat
             if (up_total > up_cap && !overflow)
             { // copies and kernels of this call are still on their way into arrays the next call may replace: both streams drained first
                 (void)hipStreamSynchronize(copy_stream);
-                (void)hipStreamSynchronize(copy_stream2);
+                if (copy_stream2) (void)hipStreamSynchronize(copy_stream2);
                 (void)hipStreamSynchronize(stream);
                 return fail(ADSB_AMD_EHIP, "UAT uplink payload area too small");
             }
@@ -945,9 +960,13 @@ struct adsb_amd_uat
                 pipe_cv.wait(lk, [&] { return pipe_stop || j->queued; });
                 if (pipe_stop) return;
             }
-            side((uint64_t)s)->in_pipeline = true;
-            const int rc = device_ok ? side((uint64_t)s)->scan(j->in, j->n, false) : side((uint64_t)s)->fail(ADSB_AMD_EHIP, "hipSetDevice failed on a pipeline worker");
-            side((uint64_t)s)->in_pipeline = false;
+            adsb_amd_uat* const sd   = side((uint64_t)s);
+            const hipStream_t   keep = sd->stream;
+            if (s == 0) sd->stream = pipe_stream[0]; // (side 0 is this handle: its own stream is for calls on their own)
+            sd->in_pipeline = true;
+            const int rc = device_ok ? sd->scan(j->in, j->n, false) : sd->fail(ADSB_AMD_EHIP, "hipSetDevice failed on a pipeline worker");
+            sd->in_pipeline = false;
+            sd->stream      = keep;
             {
                 std::lock_guard<std::mutex> lk(pipe_mu);
                 j->rc = rc, j->queued = false, j->done = true;
@@ -959,14 +978,19 @@ struct adsb_amd_uat
     int submit(const uint16_t* in_dev, uint64_t n, uint64_t stream_offset)
     {
         if (submitted - collected >= (uint64_t)kSides) return fail(ADSB_AMD_ESTATE, "as many UAT calls as the handle has buffer sets are in flight already: collect one first");
-        for (auto& twin : twins)
-            if (!twin)
+        if (!pipe_stream[0])
+        { // the three sides' compute streams, one after the other (see pipe_stream)
+            UAT_HIP(hipSetDevice(device));
+            for (auto& ps : pipe_stream) UAT_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+        }
+        for (size_t t = 0; t < sizeof(twins) / sizeof(twins[0]); t++)
+            if (auto& twin = twins[t]; !twin)
             {
                 twin.reset(new adsb_amd_uat());
                 twin->device = device;
                 twin->host_loop_only = host_loop_only;
                 twin->extra_cap = extra_cap;
-                const int rc = twin->init();
+                const int rc = twin->init(pipe_stream[t + 1]);
                 if (rc)
                 {
                     error = twin->error;
