@@ -553,7 +553,7 @@ def test_sharded_step_with_a_world_of_one_over_rccl(native_libs):
     """bench.py's N > 1 step (scan, hand-over of the packed records through node-shared page-locked memory with its credits, the step's
     header through the control page) run once with one rank over RCCL: the rank is seen through the control page and by the collective
     backend, and both record transports deliver the same records.  What the sharded step costs beside the plain one
-    (`sharded_over_plain`, 0.989 in profiles/r04_sharded_world_of_one.txt) is a figure of the bench line; the suite only holds it above 0.90."""
+    (`sharded_over_plain`, 0.95 in round 6) is a figure of the bench line; the suite only holds it above 0.85."""
     import json
     import os
     import sys
@@ -563,9 +563,10 @@ def test_sharded_step_with_a_world_of_one_over_rccl(native_libs):
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["ranks_seen"] == 1 and line["rccl_ranks_seen"] == 1 and line["record_transports_agree"] in (True, None)
-    # a loose gate (round 4 measured 0.989, profiles/r04_sharded_world_of_one.txt; boxes and contexts differ by a few per cent): a collective or a
-    # wait put back into the per-step path costs tens of per cent and fails here
-    assert line["sharded_over_plain"] is not None and line["sharded_over_plain"] >= 0.90, line["sharded_over_plain"]
+    # a loose gate (round 6 measures 0.947 - 0.956 on one box, three runs -- the plain loop it is held against got faster: it now resubmits a slot beside
+    # its copy; round 4: 0.989, profiles/r04_sharded_world_of_one.txt; boxes and contexts differ by a few per cent): a collective or a wait put back into
+    # the per-step path costs tens of per cent and fails here
+    assert line["sharded_over_plain"] is not None and line["sharded_over_plain"] >= 0.85, line["sharded_over_plain"]
 
 
 def test_device_field_decoder_equals_the_host_build(scanner):
