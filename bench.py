@@ -356,6 +356,20 @@ def bench_1090_single(args, local_rank, A, synth, torch):
     nrec_mean = run.delivered[0] / max(1, run.delivered[1])  # == nrec unless --rotate K > 1 (the K inputs hold different frames)
     rec = rec.view(np.uint8).copy().view(rec.dtype)  # a byte copy (numpy copies a structured array field by field)
 
+    # The scan kernel by itself, live: 24 scans one at a time (their ordering pass a launch of its own, no copy beside the kernel) with events on every
+    # dispatch -- what rocprofv3 of `bench.py --serial` reads (profiles/), and what the kernel_ms of rounds 1-5 stood for before the pass moved in.
+    scan_alone = None
+    if not args.serial:
+        sc.set_timing(1)
+        alone = []
+        for i in range(24):
+            sc.submit(rotation[i % len(rotation)].data_ptr(), nbytes, BB, stream, 0)
+            sc.fetch_packed(0, copy=False)
+            tm = sc.timing_if_timed(0)
+            if tm is not None and i >= 4:
+                alone.append(tm[0])
+        if alone:
+            scan_alone = sum(alone) / len(alone)
     samples = nbytes // 2
     kernel_ms = k_ms / k_n
     alg_bytes = 2.0 * samples + 32.0 * nrec_mean
@@ -416,6 +430,10 @@ def bench_1090_single(args, local_rank, A, synth, torch):
                                          "engine moves the previous step's records to the host beside it (2-5 %%) -- rocprofv3 of `bench.py --serial` (profiles/) has "
                                          "neither in or beside the scan kernel (the pass is a launch of its own there) and reads that much lower" % (k_n, args.steps, args.time_every),
                      "kernel_ms_first_100": round(k100 / max(1, n100), 4),
+                     "scan_alone": None if scan_alone is None else {
+                         "kernel_ms": round(scan_alone, 4), "frac": round((2.0 * samples + 32.0 * nrec_mean) / (scan_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "what": "the same kernel with nothing in front of it and no copy beside it: 20 scans one at a time after the timed region, HIP events on every "
+                                 "dispatch (the figure rocprofv3 of `bench.py --serial` agrees with; rounds 1-5's kernel_ms was this kernel without the ordering pass)"},
                      "algorithmic_bytes": int(alg_bytes)},
         "records_per_step": nrec, "frames_injected": injected,
         "decoded_msgs_per_step_rank0": int(accepted),
