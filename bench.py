@@ -656,9 +656,12 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
     # (shard.RootGather: xGMI to rank 0's GPU, then its one host link) rank 0's PCIe link carries N x 9 MB per step and bounds the job
     # from N = 2 on.  --rccl-gather, or a node where the shared segment cannot be set up, uses the record gather.
     ng = None
+    # the GPUs write the shared segments themselves: always over RCCL, and in the one-GPU rehearsal too (gloo only carries the set-up
+    # collectives there; the record path -- registration of each rank's pages, N contexts copying into them, headers, credits -- is the real one)
+    dma = on_device or bool(args.rehearse_on_one_gpu)
     if not args.rccl_gather:
         try:
-            ng = NodeGather(cap, dtype=A.PACKED_DTYPE)
+            ng = NodeGather(cap, dtype=A.PACKED_DTYPE, device_writes=dma)
         except OSError as e:
             if rank == 0:
                 print("bench: node-shared record segments unavailable (%s), gathering the records over RCCL" % e, file=sys.stderr)
@@ -693,7 +696,7 @@ def bench_1090_sharded(args, rank, local_rank, world, dist, A, synth, torch):
         wd.phase("acquire segment", step)
         ng.acquire(step)
         wd.phase("hand-over", step)
-        if on_device:
+        if dma:
             with torch.cuda.stream(comm):
                 n = sc.fetch_device(slot, ng.records_ptr(step), cap, comm.cuda_stream, packed=True)
                 ev = comm.record_event()

@@ -174,12 +174,17 @@ class NodeGather:
     #                        count, first buffer, rank, step (two per rank like the segments: a rank may be a step ahead of the root's reading)
     _fail_rank_for_tests = None  # (rank, stage): that rank fails at that stage of the construction ("file", "map", "register")
 
-    def __init__(self, cap_records, root=0, group=None, tag=None, acquire_timeout_s=120.0, dtype=RECORD_DTYPE):
+    def __init__(self, cap_records, root=0, group=None, tag=None, acquire_timeout_s=120.0, dtype=RECORD_DTYPE, device_writes=None):
+        """device_writes: the ranks' GPUs write the segments (each rank registers its own two with the HIP runtime).  Default: whether the
+        group's backend is "nccl".  True under gloo is the one-GPU-box rehearsal: N processes, every one's GPU context copying into its
+        own registered pages of the shared file, the root reading all of them unregistered -- the production data path with gloo only
+        for the set-up collectives."""
         assert np.dtype(dtype).itemsize == REC
         self.dtype = np.dtype(dtype)  # RECORD_DTYPE, or PACKED_DTYPE (same size, same first 18 bytes)
         self.group, self.root, self.cap = group, root, int(cap_records)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.on_device = dist.get_backend(group) == "nccl"
+        self.device_writes = self.on_device if device_writes is None else bool(device_writes)
         self.acquire_timeout_s = float(acquire_timeout_s)
         assert self._SLOT0 + self._SLOT * 2 * self.world <= self.PAGE // 8, "the control page holds %d ranks' headers" % ((self.PAGE // 8 - self._SLOT0) // self._SLOT // 2)
         self.seg = -(-self.cap * REC // self.PAGE) * self.PAGE  # whole pages: a rank registers its segments alone
@@ -238,7 +243,7 @@ class NodeGather:
                 for step in (0, 1):  # first touch of this rank's own segments (on the NUMA node this rank runs on)
                     o = self._offset(self.rank, step)
                     self._np[o:o + self.seg] = 0
-                if self.on_device:
+                if self.device_writes:
                     if fails("register"):
                         raise OSError("forced failure (test)")
                     for step in (0, 1):
@@ -319,7 +324,7 @@ class NodeGather:
         rank's header of the step is there -- so that it can enqueue step k + 1 before it looks at step k, like the other ranks do."""
         if count > self.cap:
             raise RuntimeError("rank %d produced %d records, its segment holds %d" % (self.rank, count, self.cap))
-        if event is None and self.on_device:
+        if event is None and self.device_writes:
             event = torch.cuda.current_stream().record_event()  # the records were copied on the current stream (the documented use)
         self._posted.append((int(step), int(count), int(first_buffer), event))
         if wait or event is None:
