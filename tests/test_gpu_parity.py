@@ -428,6 +428,9 @@ def test_bench_sharded_file_step_two_ranks_rehearsal(native_libs, tmp_path):
     H.assert_streams_equal(z["frames"], z["aircraft"], ofr, oac)
     assert line["decoded_msgs_per_step"] == len(ofr) and line["ranks_seen"] == 2 and line["end_to_end_msamples_per_s"] > 0
     assert len(line["kernel_ms_by_rank"]["all"]) == 2
+    # round 6: the rehearsal takes the production record path -- each of the two processes registers its own segments of the shared file and its
+    # GPU context writes them, rank 0 reads both unregistered -- and the records gathered the other way (host side here) are the same bytes
+    assert line["record_transport_by_rank"] == ["NodeGather", "NodeGather"] and line["record_transports_agree"] is True
 
 
 def _gpu_count():
