@@ -856,6 +856,33 @@ struct OutputsGuard
 };
 } // namespace
 
+// Staging of the recorded-file replay (adsb_amd_handler_replay_file): the handler's, set up by the first replay and kept -- libadsb replays a
+// file over and over (RTLSDR.hpp:419-442 re-opens it until stopped), and page-locking and releasing the buffers is a fifth of one pass.
+struct ReplayStaging
+{
+    static constexpr int    kPinned = 4, kStage = 3;
+    static constexpr size_t kSlice  = 64; // buffers per batch (16 MiB)
+    uint8_t*                stage[kStage]   = {};
+    uint8_t*                pinned[kPinned] = {};
+    hipStream_t             up_stream       = nullptr;
+    bool reserve(size_t nbatch)
+    {
+        const size_t bytes = kSlice * ADSB_AMD_REF_BUFFER_BYTES;
+        bool         ok    = up_stream || hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < kStage && (size_t)i < nbatch; i++) ok = stage[i] || hipMalloc(&stage[i], bytes) == hipSuccess;
+        for (int i = 0; ok && i < kPinned && (size_t)i < nbatch; i++) ok = pinned[i] || hipHostMalloc(&pinned[i], bytes, hipHostMallocDefault) == hipSuccess;
+        return ok;
+    }
+    void release()
+    {
+        for (uint8_t*& p : stage)
+            if (p) (void)hipFree(p), p = nullptr;
+        for (uint8_t*& p : pinned)
+            if (p) (void)hipHostFree(p), p = nullptr;
+        if (up_stream) (void)hipStreamDestroy(up_stream), up_stream = nullptr;
+    }
+};
+
 struct adsb_amd_handler
 {
     adsb_amd_ctx*                  ctx = nullptr;
@@ -863,6 +890,7 @@ struct adsb_amd_handler
     std::vector<adsb_amd_record_t> scratch;
     bool                           want_frames = true; // false: records travel in the packed form, callbacks get frames without message bytes
     std::string                    error;
+    ReplayStaging                  replay;
 };
 
 extern "C" int adsb_amd_handler_create(adsb_amd_handler_t** out, int device) { return adsb_amd_handler_create_mode(out, device, ADSB_AMD_MODE_2000); }
@@ -887,6 +915,7 @@ extern "C" int adsb_amd_handler_create_mode(adsb_amd_handler_t** out, int device
 extern "C" void adsb_amd_handler_destroy(adsb_amd_handler_t* h)
 {
     if (!h) return;
+    if (h->ctx && hipSetDevice(h->ctx->device) == hipSuccess) h->replay.release();
     adsb_amd_destroy(h->ctx);
     delete h;
 }
@@ -967,75 +996,79 @@ extern "C" long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* 
         return 0;
     }
     const size_t nbuf = std::min(max_buffers, total - first_buffer);
-    const size_t   kSlice = 256; // buffers per batch (64 MiB)
-    const size_t   nbatch = (nbuf + kSlice - 1) / kSlice;
-    adsb_amd_ctx*  c      = h->ctx;
-    // Two device staging buffers, two page-locked host buffers and an uploader thread: while the GPU scans batch k and this thread
-    // resolves batch k-1, the uploader reads batch k+1 (pread by eight threads straight into page-locked memory: from the page
-    // cache that is a copy at memory speed, and the upload that follows is a DMA; handing the runtime a mapping of the file
-    // instead was measured at 7.7 GB/s) and sends it to the device.  Buffers stay independent (a batch is a whole number of them),
-    // the resolver sees the batches in file order, so the callback stream is the one of buffer-by-buffer delivery.
-    uint8_t* stage[2] = {nullptr, nullptr};
-    uint8_t* pinned[2] = {nullptr, nullptr};
-    long     accepted = 0;
-    auto     cleanup  = [&]() {
-        for (uint8_t* p : stage)
-            if (p) (void)hipFree(p);
-        for (uint8_t* p : pinned)
-            if (p) (void)hipHostFree(p);
-        close(fd);
-    };
-    if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&stage[0], kSlice * BB) != hipSuccess || hipMalloc(&stage[1], kSlice * BB) != hipSuccess ||
-        hipHostMalloc(&pinned[0], kSlice * BB, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&pinned[1], kSlice * BB, hipHostMallocDefault) != hipSuccess)
+    constexpr size_t kSlice = ReplayStaging::kSlice;
+    const size_t     nbatch = (nbuf + kSlice - 1) / kSlice;
+    adsb_amd_ctx*    c      = h->ctx;
+    // Three stages beside this thread, each a batch ahead of the next: reader threads copy batch k+2 out of the page cache into page-locked
+    // memory (pread straight into it: a copy at memory speed; handing the runtime a mapping of the file instead was measured at 7.7 GB/s),
+    // the uploader sends batch k+1 to the device (one DMA), the GPU scans batch k and this thread resolves batch k-1.  Until round 6 the
+    // reading and the upload of a batch ran one after the other on one thread, eight reader threads were started per batch, the batches
+    // were 64 MiB (256 MiB of page-locked and device memory set up and released per call), and with two device buffers an upload could
+    // not start before the batch two behind it was resolved: 68 ms per GiB, now 29-31 (profiles/r06_replay.txt).  Buffers stay independent
+    // (a batch is a whole number of them), the resolver sees the batches in file order, so the callback stream is the one of
+    // buffer-by-buffer delivery.
+    constexpr int   kPinned = ReplayStaging::kPinned, kStage = ReplayStaging::kStage, kReaders = 8;
+    long            accepted = 0;
+    if (hipSetDevice(c->device) != hipSuccess || !h->replay.reserve(nbatch))
     {
         h->error = "replay_file: cannot allocate the staging buffers";
-        cleanup();
+        h->replay.release();
+        close(fd);
         return ADSB_AMD_EHIP;
     }
+    uint8_t* const* const stage     = h->replay.stage;
+    uint8_t* const* const pinned    = h->replay.pinned;
+    const hipStream_t     up_stream = h->replay.up_stream;
     std::mutex              mu;
     std::condition_variable cv;
-    size_t                  uploaded = 0, released = 0; // batches whose upload is complete / whose staging buffer is free again
+    std::vector<int>        read_parts(nbatch, 0);      // reader threads done with their part of a batch
+    size_t                  uploaded = 0, released = 0; // batches whose upload is complete / whose device staging buffer is free again
     std::atomic<bool>       failed{false};
-    std::thread             uploader([&]() {
-        if (hipSetDevice(c->device) != hipSuccess) failed = true;
+    auto                    fail = [&]() {
+        std::unique_lock lk(mu);
+        failed = true;
+        cv.notify_all();
+    };
+    std::thread readers[kReaders];
+    for (int t = 0; t < kReaders; t++)
+        readers[t] = std::thread([&, t]() {
+            for (size_t b = 0; b < nbatch && !failed; b++)
+            {
+                {
+                    std::unique_lock lk(mu);
+                    cv.wait(lk, [&]() { return b < uploaded + (size_t)kPinned || failed; }); // the page-locked buffer's last upload is done
+                    if (failed) return;
+                }
+                const size_t bytes = std::min(kSlice, nbuf - b * kSlice) * BB;
+                const off_t  at    = (off_t)((first_buffer + b * kSlice) * BB);
+                size_t       lo = bytes * (size_t)t / kReaders, hi = bytes * (size_t)(t + 1) / kReaders;
+                while (lo < hi)
+                {
+                    const ssize_t r = pread(fd, pinned[b % kPinned] + lo, hi - lo, at + (off_t)lo);
+                    if (r <= 0) return fail();
+                    lo += (size_t)r;
+                }
+                std::unique_lock lk(mu);
+                if (++read_parts[b] == kReaders) cv.notify_all();
+            }
+        });
+    std::thread uploader([&]() {
+        if (hipSetDevice(c->device) != hipSuccess) return fail();
         for (size_t b = 0; b < nbatch && !failed; b++)
         {
             {
                 std::unique_lock lk(mu);
-                cv.wait(lk, [&]() { return b < released + 2 || failed; });
-                if (failed) break;
+                cv.wait(lk, [&]() { return (read_parts[b] == kReaders && b < released + (size_t)kStage) || failed; });
+                if (failed) return;
             }
-            const size_t n     = std::min(kSlice, nbuf - b * kSlice);
-            const size_t bytes = n * BB;
-            const off_t  at    = (off_t)((first_buffer + b * kSlice) * BB);
-            {
-                constexpr int    kReaders = 8;
-                std::atomic<int> bad{0};
-                std::thread      rd[kReaders];
-                for (int t = 0; t < kReaders; t++)
-                    rd[t] = std::thread([&, t]() {
-                        size_t lo = bytes * (size_t)t / kReaders, hi = bytes * (size_t)(t + 1) / kReaders;
-                        while (lo < hi)
-                        {
-                            const ssize_t r = pread(fd, pinned[b & 1] + lo, hi - lo, at + (off_t)lo);
-                            if (r <= 0)
-                            {
-                                bad = 1;
-                                return;
-                            }
-                            lo += (size_t)r;
-                        }
-                    });
-                for (auto& t : rd) t.join();
-                if (bad) failed = true;
-            }
-            if (!failed && hipMemcpy(stage[b & 1], pinned[b & 1], bytes, hipMemcpyHostToDevice) != hipSuccess) failed = true;
+            const size_t bytes = std::min(kSlice, nbuf - b * kSlice) * BB;
+            if (hipMemcpyAsync(stage[b % kStage], pinned[b % kPinned], bytes, hipMemcpyHostToDevice, up_stream) != hipSuccess ||
+                hipStreamSynchronize(up_stream) != hipSuccess)
+                return fail();
             std::unique_lock lk(mu);
             uploaded = b + 1;
             cv.notify_all();
         }
-        std::unique_lock lk(mu);
-        cv.notify_all();
     });
     auto resolve = [&](size_t b) -> int { // batch b was submitted on slot b & 1
         const adsb_amd_record_t*  rec = nullptr;
@@ -1063,7 +1096,7 @@ extern "C" long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* 
             if (failed) break;
         }
         const size_t n = std::min(kSlice, nbuf - b * kSlice);
-        rc             = adsb_amd_scan_1090_submit(c, stage[b & 1], n * BB, BB, c->stream, (int)(b & 1));
+        rc             = adsb_amd_scan_1090_submit(c, stage[b % kStage], n * BB, BB, c->stream, (int)(b & 1));
         if (!rc && b > 0) rc = resolve(b - 1);
     }
     if (!rc && !failed && nbatch > 0) rc = resolve(nbatch - 1);
@@ -1073,6 +1106,7 @@ extern "C" long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* 
         cv.notify_all();
     }
     uploader.join();
+    for (auto& t : readers) t.join();
     (void)hipDeviceSynchronize();
     for (Slot& sl : c->slot) sl.pending = false; // a failed run may leave a submitted scan behind
     if (failed && !rc)
@@ -1080,7 +1114,7 @@ extern "C" long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* 
         h->error = "replay_file: upload failed";
         rc       = ADSB_AMD_EHIP;
     }
-    cleanup();
+    close(fd);
     return rc ? rc : accepted;
 }
 
