@@ -288,7 +288,8 @@ int64_t adsb_amd_shm_load_acquire(const int64_t* word);
 /* Recorded-file replay, one pass: what RTLSDR::TestDataReadLoop (RTLSDR.hpp:419-442) feeds a handler -- whole 262144-byte
  * buffers in file order, each demodulated on its own, a trailing partial buffer never delivered -- over buffers
  * [first_buffer, first_buffer + max_buffers) of the file (ranks of a multi-GPU job take disjoint ranges; the resolver state
- * of this handler carries across the whole range).  Returns the number of accepted frames or a negative error. */
+ * of this handler carries across the whole range; a frame's `offset` counts samples from the first buffer of the pass, as if the whole
+ * range had been one HandleData call).  Returns the number of accepted frames or a negative error. */
 long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* path, size_t first_buffer, size_t max_buffers, adsb_amd_on_changed_fn cb,
                                   void* user);
 

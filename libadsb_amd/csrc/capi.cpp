@@ -1078,7 +1078,9 @@ extern "C" long adsb_amd_handler_replay_file(adsb_amd_handler_t* h, const char* 
         int rc = h->want_frames ? adsb_amd_scan_1090_fetch_decoded(c, (int)(b & 1), &rec, &dec, &nr) : adsb_amd_scan_1090_fetch_packed(c, (int)(b & 1), &pk, &nr);
         if (rc) return rc;
         const size_t n = std::min(kSlice, nbuf - b * kSlice);
+        h->resolver.set_frame_offset_base(b * kSlice * (BB / 2)); // a frame's offset counts from the first buffer of the pass, whatever the batches are
         const long   a = h->want_frames ? h->resolver.feed(rec, dec, nr, BB / 2, n, cb, user) : h->resolver.feed_packed(pk, nr, BB / 2, n, cb, user);
+        h->resolver.set_frame_offset_base(0);
         if (a < 0) return (int)a;
         accepted += a;
         std::unique_lock lk(mu);

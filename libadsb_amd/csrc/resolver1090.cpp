@@ -429,7 +429,7 @@ void Resolver1090::update_pass(Block& blk, const Job& job, adsb_amd_on_changed_f
         if (cb)
         {
             adsb_amd_frame_t fr{};
-            fr.offset = static_cast<uint64_t>(r.buffer) * job.samples_per_buffer + r.offset;
+            fr.offset = frame_base_ + static_cast<uint64_t>(r.buffer) * job.samples_per_buffer + r.offset;
             if (!packed) std::memcpy(fr.msg, job.rec[i].msg, 14);
             fr.nbits         = r.nbits;
             fr.errorbit      = r.errorbit;

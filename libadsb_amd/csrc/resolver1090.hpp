@@ -51,6 +51,9 @@ class Resolver1090
     // the same from the packed hand-over form (no message bytes: the frames passed to the callback have msg all zero)
     long   feed_packed(const adsb_amd_packed_t* packed, size_t n, size_t samples_per_buffer, size_t nbuffers, adsb_amd_on_changed_fn cb, void* user);
     size_t aircraft_count() const { return table_.size(); }
+    // Added to the `offset` of every frame handed to the callback by the next feed: a caller that cuts one delivery into several feeds (the
+    // recorded-file replay's batches) keeps the frames' sample indices those of the whole delivery.
+    void   set_frame_offset_base(uint64_t samples) { frame_base_ = samples; }
 
   private:
     // What the sequential pass reads and writes per aircraft: the reference's ICAO cache entry (:195-207) and the raw halves of the
@@ -163,6 +166,7 @@ class Resolver1090
     uint64_t  ns_per_sample_ = 0; // 10^9 / rate when that is a whole number (2 MS/s: 500), else 0
     uint64_t  rate_recip_  = 0;   // floor(2^64 / rate): quotient estimate for the exact division by the rate
     uint64_t  stream_base_ = 0;
+    uint64_t  frame_base_  = 0;
     uint32_t  per_us_x10_  = 20; // samples per microsecond x 10 of the records (skip-ahead length)
 };
 

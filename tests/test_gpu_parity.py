@@ -224,6 +224,31 @@ def test_replay_file_matches_oracle_and_drops_the_partial_buffer(native_libs, tm
     h.close()
 
 
+def test_replay_file_over_many_batches_and_twice_on_one_handler(native_libs, tmp_path):
+    """The replay's stages (readers -> uploader -> scan -> resolver, capi.cpp) keep four page-locked and three device staging buffers of 64
+    reference buffers each: a 330-buffer file (six batches, the last one partial) goes round every ring, and the callback stream must still be
+    the oracle's for the whole file in file order.  The staging is the handler's: a second pass on the same handler re-uses it, and -- like the
+    reference, whose handler keeps its aircraft and ICAO state while RTLSDR re-opens the file -- continues the same stream."""
+    nbuf = 330
+    iq, _ = synth.fill_range(7, nbuf)
+    path = tmp_path / "1090000000.test.dat"
+    iq.tofile(path)
+    h = A.Handler1090()
+    n, fr, ac = h.replay_file(str(path))
+    ofr, oac = H.oracle_run(iq, BB)
+    assert n == len(fr) == len(ofr) > 5000
+    H.assert_streams_equal(fr, ac, ofr, oac)
+    n2, fr2, ac2 = h.replay_file(str(path), first_buffer=100, max_buffers=200)  # four batches (the last partial) through the staging as it stands
+    h.close()
+    # one stream: the whole file, then buffers 100..299 again, through one handler state
+    both = np.concatenate([iq, iq[100 * BB:300 * BB]])
+    ofr_b, oac_b = H.oracle_run(both, BB)
+    assert n + n2 == len(ofr_b)
+    fr2 = fr2.copy()
+    fr2["offset"] += nbuf * (BB // 2)  # a frame's offset counts from the first buffer of ITS pass (whatever the batches are): here 100 -> 0
+    H.assert_streams_equal(np.concatenate([fr, fr2]), np.concatenate([ac, ac2]), ofr_b, oac_b)
+
+
 def test_full_size_1gib_equals_oracle_on_every_buffer(scanner):
     """BASELINE configs[1]+[2] at full size: 4096 reference buffers (1 GiB) in one scan.  Size-independent properties
     (shard invariance, strict order, parity consistency) plus exact equality with the oracle on all 4096 buffers."""
