@@ -313,6 +313,42 @@ def test_pipelined_loop_with_a_resubmit_beside_every_copy_delivers_each_steps_ow
         sc.close()
 
 
+def test_split_fetch_refuses_calls_out_of_order(native_libs):
+    """adsb_amd_scan_1090_fetch_packed_begin / _end: a begin without a submit, a second begin before the end, an end without a begin, a slot that
+    does not exist and a scan that did not produce the packed form are refused with a state / argument error and leave the context usable."""
+    import torch
+    iq, _ = synth.fill_range(90, 8)
+    d = torch.from_numpy(iq).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    sc = A.Scanner()
+    sc.set_outputs(A.OUT_PACKED)
+    with pytest.raises(A.AdsbAmdError, match="fetch without submit"):
+        sc.fetch_packed_begin(0)
+    with pytest.raises(A.AdsbAmdError, match="no fetch begun"):
+        sc.fetch_packed_end(0)
+    with pytest.raises(A.AdsbAmdError, match="slot must be"):
+        sc.fetch_packed_begin(A.SLOTS if hasattr(A, "SLOTS") else 3)
+    sc.submit(d.data_ptr(), d.numel(), BB, st, 1)
+    n = sc.fetch_packed_begin(1)
+    sc.submit(d.data_ptr(), d.numel(), BB, st, 1)  # the slot's next scan beside the copy: allowed, that is the point of the split
+    with pytest.raises(A.AdsbAmdError, match="begun and not ended"):
+        sc.fetch_packed_begin(1)
+    first = sc.fetch_packed_end(1, copy=True)
+    assert len(first) == n > 0
+    with pytest.raises(A.AdsbAmdError, match="no fetch begun"):
+        sc.fetch_packed_end(1)
+    again = sc.fetch_packed(1, copy=True)  # the scan submitted beside the copy (the refused begin has not consumed it)
+    assert again.tobytes() == first.tobytes()
+    sc.set_outputs(A.OUT_RECORDS)
+    sc.submit(d.data_ptr(), d.numel(), BB, st, 0)
+    with pytest.raises(A.AdsbAmdError, match="did not produce the packed form"):
+        sc.fetch_packed_begin(0)
+    sc.set_outputs(A.OUT_PACKED)
+    sc.submit(d.data_ptr(), d.numel(), BB, st, 0)
+    assert sc.fetch_packed(0, copy=True).tobytes() == first.tobytes()
+    sc.close()
+
+
 @pytest.mark.parametrize("seed", range(5))
 def test_fuzzed_threshold_cases(scanner, seed):
     """Buffers built to sit on the slicer's thresholds: samples from a small alphabet (many exact ties), frames whose pulse
