@@ -70,6 +70,8 @@ def parse_args(argv=None):
                     "can serve it (K = 1, the default, rescans one resident input; profiles/r06_rotate.txt holds the A/B)")
     ap.add_argument("--depth", type=int, default=2, help="N = 1: scans on the stream at any time in the pipelined loop (2, the default, or 3: the context has three "
                     "result slots; measured no faster, profiles/r06_ordering_in_kernel.txt)")
+    ap.add_argument("--streams", type=int, default=1, help="N = 1: the scans of the pipelined loop alternate over this many streams (with 2 and --depth 3 a "
+                    "scan kernel may start while the one before it drains; its ordering pass then rides in front of the kernel two steps on, the next one on its stream)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the end_to_end and uat978 blocks (profiling runs)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N > 1 ranks all on cuda:0 with the gloo backend: exercises the "
                     "multi-rank code path (sharding, record gather, resolve) on a one-GPU box; the numbers mean nothing")
@@ -245,6 +247,7 @@ def main():
 
 def make_runner(args, sc, d_iq, BB, stream):
     inputs = d_iq if isinstance(d_iq, (list, tuple)) else [d_iq]  # --rotate K: step i scans inputs[i mod K]
+    streams = [stream] + list(getattr(args, "more_streams", []))  # --streams S: step i is launched on stream i mod S
     nbytes = inputs[0].numel()
     seen = [0]  # steps submitted so far by this runner (the rotation goes on across calls of run)
     made = [0, 0]  # records delivered, steps delivered (the inputs of a rotation differ in their record counts)
@@ -291,12 +294,12 @@ def make_runner(args, sc, d_iq, BB, stream):
         # scan beside the copy (a scan writes the slot's raw regions only), then wait for the copy.
         depth = max(1, min(3, getattr(args, "depth", 2)))
         for k in range(min(depth, steps)):
-            sc.submit(ptr(), nbytes, BB, stream, k)
+            sc.submit(ptr(), nbytes, BB, streams[k % len(streams)], k)
         for i in range(steps):
             sc.fetch_packed_begin(i % depth)
             note(i % depth)
             if i + depth < steps:
-                sc.submit(ptr(), nbytes, BB, stream, i % depth)
+                sc.submit(ptr(), nbytes, BB, streams[(i + depth) % len(streams)], i % depth)
             rec = took(sc.fetch_packed_end(i % depth, copy=False))
         return rec, acc[0], acc[1], acc[2]
     run.delivered = made
@@ -327,6 +330,11 @@ def bench_1090_single(args, local_rank, A, synth, torch):
     sc.set_outputs(A.OUT_PACKED)  # the throughput path hands over record head + decoded fields, 32 bytes, no message bytes
     stream = torch.cuda.current_stream().cuda_stream
     nbytes = d_iq.numel()
+    # (made here, before the first launch: which hardware queue a stream lands on follows the order in which the process makes its streams, and one made
+    # late can share a queue with the scanner's copy stream or with the first stream -- no two kernels side by side then; DESIGN section 9.3 has the UAT case)
+    more_streams = [torch.cuda.Stream() for _ in range(max(2, args.streams) - 1)]
+    side_stream = more_streams[0]
+    args.more_streams = [t.cuda_stream for t in more_streams[:max(1, args.streams) - 1]]
     run = make_runner(args, sc, rotation, BB, stream)
     if args.rate != 20:
         args.no_extras = True  # end-to-end and CPU legs are defined on the parity-green workload only
@@ -371,6 +379,28 @@ def bench_1090_single(args, local_rank, A, synth, torch):
         if alone:
             scan_alone = sum(alone) / len(alone)
     samples = nbytes // 2
+    # The same loop with the scans alternating over TWO streams and three result slots in flight (--streams 2 --depth 3), once, after the timed region:
+    # a scan kernel then starts while the one before it drains (its waves take the CUs' wave slots as the older kernel's persistent waves leave), and a
+    # step's ordering pass rides in front of the kernel two steps on, the next one on its stream.  Reported beside the headline, not as it: events on
+    # overlapping dispatches no longer read a kernel's own duration (kernel_ms would say 0.35 ms), and over 20 steps the longer drain -- results arrive a
+    # kernel later -- takes back what the steady state gains (profiles/r06_two_streams.txt).
+    overlapped = None
+    if not args.serial and sc.has_split_fetch() and args.streams == 1 and not args.no_extras:
+        args.more_streams, depth0 = [side_stream.cuda_stream], args.depth
+        args.depth = 3
+        run2 = make_runner(args, sc, rotation, BB, stream)
+        sc.set_timing(0)
+        run2(SETUP_STEPS)  # (the scans one at a time just before left the clocks where an idle period leaves them: kernel_ms_first_100)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        rec2, _, _, _ = run2(100)
+        torch.cuda.synchronize()
+        sec2 = (time.perf_counter() - t2) / 100
+        overlapped = {"streams": 2, "depth": 3, "steps": 100, "ms_per_step": round(sec2 * 1e3, 4), "msamples_per_s": round(samples / sec2 / 1e6, 1),
+                      "records_match_the_timed_loop": bool(len(rec2) == nrec and (len(rotation) > 1 or rec2.tobytes() == rec.tobytes())),
+                      "what": "the headline loop with the scans alternating over two streams, three in flight: a kernel starts while the one before it drains; "
+                              "steady state only (100 steps after %d untimed)" % SETUP_STEPS}
+        args.more_streams, args.depth = [], depth0
     kernel_ms = k_ms / k_n
     alg_bytes = 2.0 * samples + 32.0 * nrec_mean
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -441,6 +471,7 @@ def bench_1090_single(args, local_rank, A, synth, torch):
         # host while the GPU scans step k + 1 (`pipelined`); with --serial, the slower of the two separately timed halves
         "decoded_msgs_per_s": pipe["decoded_msgs_per_s"] if pipe else round(min(accepted * args.steps / elapsed, accepted / max(resolve_s, 1e-9)), 1),
         "pipelined": pipe,
+        "overlapped": overlapped,
         "gpu_enqueue_to_count_ms": round(t_ms / k_n, 4),
         "host_resolve_ms_rank0": round(resolve_s * 1e3, 2),
         "host_resolve_note": "records + GPU-decoded fields -> ICAO gating, skip-ahead (helper thread) | batched CPR, aircraft update (calling thread), no listener; best of 5 stretches",

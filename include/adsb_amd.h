@@ -166,7 +166,10 @@ int adsb_amd_scan_1090(adsb_amd_ctx_t* ctx, const uint8_t* iq_host, size_t nbyte
  * context's result buffers so that the device->host copy of one scan overlaps the kernels of the next (two slots do; a third lets a loop keep
  * three scans on the stream; a slot's device arrays are made when it is first used).  `iq_device` must be
  * 16-byte aligned and stay valid until the matching fetch.  `hip_stream` is a hipStream_t
- * (NULL: the context's own stream).
+ * (NULL: the context's own stream).  A scan's ordering pass is done by the next scan kernel submitted on the SAME stream (in front of its own
+ * work), or by a launch of its own when the scan is fetched first.  A loop may therefore alternate its submits over two streams with three slots
+ * in flight: a scan kernel then starts while the one before it drains, and the step costs what the kernel alone costs (profiles/r06_two_streams.txt);
+ * the fetch order, and the rule that a slot's next submit follows its fetch (or fetch_packed_begin), stay as they are.
  */
 #define ADSB_AMD_SLOTS 3
 int adsb_amd_scan_1090_submit(adsb_amd_ctx_t* ctx, const void* iq_device, size_t nbytes, size_t buffer_bytes,

@@ -274,20 +274,23 @@ def test_full_size_1gib_equals_oracle_on_every_buffer(scanner):
     H.assert_records_equal(full, O.expected_records(iq, BB, dtype=A.RECORD_DTYPE))
 
 
-@pytest.mark.parametrize("depth", [2, 3])
-def test_pipelined_loop_with_a_resubmit_beside_every_copy_delivers_each_steps_own_records(native_libs, depth):
+@pytest.mark.parametrize("depth,nstreams", [(2, 1), (3, 1), (3, 2)])
+def test_pipelined_loop_with_a_resubmit_beside_every_copy_delivers_each_steps_own_records(native_libs, depth, nstreams):
     """The loop bench.py runs, on inputs that differ from step to step: two scans on the stream at any time, a step's ordering pass in front of
     the scan kernel after it (gather1090.hip.h), its count stored by the pass's last finisher, its packed records copied while the slot's NEXT scan
     is already submitted (adsb_amd_scan_1090_fetch_packed_begin / _end).  Every step's records must be that step's own -- a copy that started before
     the pass had finished, or a pass that wrote into an array still being copied, shows as records of another input -- and equal to what the same
     scanner delivers for the same input on its own (serial submit / fetch: the stand-alone pass), which the other tests hold against the oracle.
     Sizes: 1 024 buffers (256 MiB, 128 blocks of the ordering pass) and 40 buffers (a pass of 5 blocks inside a kernel of 1 280 waves).
-    With two scans on the stream (bench.py's loop) and with three (the context has three result slots)."""
+    With two scans on the stream (bench.py's loop), with three (the context has three result slots), and with three alternating over TWO streams
+    (bench.py --streams 2 --depth 3: a scan kernel starts while the one before it drains, a step's ordering pass rides in the kernel two steps on)."""
     import torch
+    side = [torch.cuda.Stream() for _ in range(nstreams - 1)]
     for nbuf, steps in ((1024, 9), (40, 7)):
         sc = A.Scanner()
         sc.set_outputs(A.OUT_PACKED)
         st = torch.cuda.current_stream().cuda_stream
+        sts = [st] + [t.cuda_stream for t in side]
         inputs, want = [], []
         for k in range(3):
             iq, _ = synth.fill_range(7000 + k * nbuf, nbuf, nthreads=16)
@@ -297,13 +300,14 @@ def test_pipelined_loop_with_a_resubmit_beside_every_copy_delivers_each_steps_ow
             want.append(sc.fetch_packed(0, copy=True))
         assert len({len(w) for w in want}) == 3  # (the three inputs hold different numbers of records: a mix-up cannot pass by count)
         got = []
+        torch.cuda.synchronize()
         for k in range(depth):
-            sc.submit(inputs[k % 3].data_ptr(), inputs[k % 3].numel(), BB, st, k)
+            sc.submit(inputs[k % 3].data_ptr(), inputs[k % 3].numel(), BB, sts[k % nstreams], k)
         for i in range(steps):
             n = sc.fetch_packed_begin(i % depth)
             if i + depth < steps:
                 d = inputs[(i + depth) % 3]
-                sc.submit(d.data_ptr(), d.numel(), BB, st, i % depth)
+                sc.submit(d.data_ptr(), d.numel(), BB, sts[(i + depth) % nstreams], i % depth)
             rec = sc.fetch_packed_end(i % depth, copy=True)
             assert len(rec) == n
             got.append(rec)
