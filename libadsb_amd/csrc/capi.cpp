@@ -57,7 +57,7 @@ struct Slot
     bool               dec_valid = false;  // host_dec holds the last fetch's decoded fields
     size_t             host_cap = 0;       // records
     size_t             chunks_cap = 0, cap_per_chunk = 0;
-    size_t             cap_hint = 0;       // region size the other slot had to grow to: this slot's next scan starts with it
+    size_t             cap_hint = 0;       // region size another slot had to grow to: this slot's next scan starts with it
     hipEvent_t         ev_scan0 = nullptr, ev_scan1 = nullptr, ev_order = nullptr;
     uint32_t           seq = 0;            // launches of this slot: the stamp the ordering pass writes beside the count
     bool               pending = false, timed = false;
@@ -474,7 +474,7 @@ extern "C" int adsb_amd_scan_1090_submit(adsb_amd_ctx_t* c, const void* iq_devic
     int      rc = make_args(c, iq_device, nbytes, buffer_bytes, &a);
     if (rc) return rc;
     size_t cap = s.cap_per_chunk ? s.cap_per_chunk : kDefaultCap;
-    if (s.cap_hint > cap) cap = s.cap_hint; // the other slot had to grow its regions for this kind of input
+    if (s.cap_hint > cap) cap = s.cap_hint; // another slot had to grow its regions for this kind of input
     if ((rc = ensure_slot(c, s, a.total_chunks, cap, c->outputs))) return rc;
     s.produced = c->outputs;
     s.args     = a;
@@ -489,7 +489,7 @@ namespace
 // Wait for the slot's scan; when a chunk produced more records than its region holds (dense noise, adversarial input) repeat the scan
 // with regions eight times larger, up to the hard bound of two records per preamble position -- as long as the record arrays
 // (regions + dense + decoded) still fit in free device memory; beyond that the call fails with ADSB_AMD_ENOMEM instead of leaning on
-// hipMalloc to refuse.  The region size that worked is remembered for BOTH slots (the other one starts its next scan with it).
+// hipMalloc to refuse.  The region size that worked is remembered for EVERY slot (the others start their next scans with it).
 // The slot's record count and overflow flag -> s.nrecords, s.overflow.
 int wait_count(adsb_amd_ctx* c, Slot& s)
 {
