@@ -397,6 +397,8 @@ def bench_1090_single(args, local_rank, A, synth, torch):
         torch.cuda.synchronize()
         sec2 = (time.perf_counter() - t2) / 100
         overlapped = {"streams": 2, "depth": 3, "steps": 100, "ms_per_step": round(sec2 * 1e3, 4), "msamples_per_s": round(samples / sec2 / 1e6, 1),
+                      # (no kernel of this loop has a duration of its own -- they overlap --, but the chip is never idle: the whole step against the roofline)
+                      "step_frac_of_hbm_peak": round((2.0 * samples + 32.0 * nrec) / sec2 / 1e9 / HBM_PEAK_GBS, 4),
                       "records_match_the_timed_loop": bool(len(rec2) == nrec and (len(rotation) > 1 or rec2.tobytes() == rec.tobytes())),
                       "what": "the headline loop with the scans alternating over two streams, three in flight: a kernel starts while the one before it drains; "
                               "steady state only (100 steps after %d untimed)" % SETUP_STEPS}
